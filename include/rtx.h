@@ -1,0 +1,275 @@
+/*
+ * rtx.h -- C ABI of librtx_hip.so, the MI355X (gfx950) implementation of the
+ * ray tracer's per-pixel hot path: closest-hit BVH traversal, ray/box and
+ * ray/triangle tests, hit attribute interpolation, Phong shading, point /
+ * segment / parallelogram light shadow rays, mirror / glossy / transparency
+ * bounces, texture and environment-map fetches, and the five frame drivers.
+ *
+ * The reference (stefan-creasta/RayTracer) has no FFI of its own: its seam for
+ * this path is the C++ class BvhInterface (src/bvh_interface.h:12-41) and the
+ * free functions of src/render.h:18-29.  Every entry point below names the
+ * reference interface it replaces.  All structs are plain data, all pointers
+ * are caller-owned, nothing is retained past return unless stated, and no
+ * exception crosses this boundary: functions return 0 on success and a
+ * negative rtx_status on failure, with text available from rtx_last_error().
+ *
+ * All arithmetic is IEEE fp32 evaluated in the reference's operation order
+ * without fused multiply-add, so hit distances and triangle ids are
+ * bit-identical to the CPU path.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtx_status {
+    RTX_OK = 0,
+    RTX_ERR_INVALID = -1,   /* bad argument / inconsistent description          */
+    RTX_ERR_DEVICE = -2,    /* a HIP runtime call failed                        */
+    RTX_ERR_LIMIT = -3,     /* a documented size limit was exceeded             */
+    RTX_ERR_NOT_INIT = -4   /* rtx_init has not succeeded on this thread's GPU  */
+} rtx_status;
+
+/* ---- feature switches: Features + ExtraFeatures, src/common.h:61-87 ------- */
+typedef struct rtx_features {
+    int32_t enable_shading;
+    int32_t enable_recursive;
+    int32_t enable_hard_shadow;
+    int32_t enable_soft_shadow;
+    int32_t enable_normal_interp;
+    int32_t enable_texture_mapping;
+    int32_t enable_accel_structure;
+    int32_t enable_environment_mapping;
+    int32_t enable_bvh_sah_binning;          /* host builder only */
+    int32_t enable_bilinear_texture_filtering;
+    int32_t enable_mipmap_texture_filtering;
+    int32_t enable_glossy_reflection;
+    int32_t reserved[4];
+} rtx_features;
+
+/* ---- ray / hit: Ray (framework/include/framework/ray.h:9-13), HitInfo
+ *      (src/common.h:14-21) -------------------------------------------------- */
+typedef struct rtx_ray {
+    float origin[3];
+    float direction[3];
+    float t;                 /* in: search limit (FLT_MAX for "none"); unchanged on return */
+} rtx_ray;
+
+#define RTX_TRI_NONE (-1)
+/* sphere i is reported as triangle id -2 - i */
+typedef struct rtx_hit {
+    float   t;               /* closest hit distance, or the input t on a miss */
+    int32_t tri;             /* index in the reference's meshTrianglePairs order
+                                (mesh-major, src/bounding_volume_hierarchy.cpp:166-175) */
+    float   normal[3];       /* HitInfo::normal as the reference leaves it (un-normalised) */
+    float   bary[3];         /* HitInfo::barycentricCoord (area ratios)        */
+    float   uv[2];           /* HitInfo::texCoord                              */
+    int32_t material;        /* index into rtx_scene_desc::materials, -1 on a miss */
+    int32_t hit;             /* 1 = hit, 0 = miss                              */
+} rtx_hit;
+
+/* ---- flattened acceleration structure -------------------------------------
+ * Built on the host by the reference's builder
+ * (src/bounding_volume_hierarchy.cpp:101-180) and flattened to 64-byte records.
+ * A child reference r >= 0 is an inner node index; r < 0 is a leaf whose
+ * triangles are records [~r, ~r + count) of the leaf-ordered triangle array. */
+typedef struct rtx_node {
+    float   lo0[3], hi0[3];  /* box of child 0 (reference "left")              */
+    float   lo1[3], hi1[3];  /* box of child 1 (reference "right")             */
+    int32_t ref0, ref1;
+    int32_t cnt0, cnt1;      /* triangle count when the child is a leaf        */
+} rtx_node;                  /* 64 B */
+
+typedef struct rtx_tri {
+    float   v0[3], v1[3], v2[3];
+    float   n[3];            /* normalize(cross(v1-v0, v2-v0)), src/intersect.cpp:50-58 */
+    float   d;               /* dot(v0, n)                                     */
+    int32_t id;              /* meshTrianglePairs index                        */
+    int32_t material;
+    int32_t pad;
+} rtx_tri;                   /* 64 B */
+
+typedef struct rtx_tri_attr {
+    float n0[3], n1[3], n2[3];   /* vertex normals                             */
+    float uv0[2], uv1[2], uv2[2];
+    float pad;
+} rtx_tri_attr;              /* 64 B, same index as rtx_tri */
+
+/* Material, framework/include/framework/mesh.h:22-34 */
+typedef struct rtx_material {
+    float   kd[3];
+    float   ks[3];
+    float   shininess;
+    float   transparency;
+    int32_t texture;         /* index into textures, -1 = none                 */
+    int32_t pad[3];
+} rtx_material;              /* 48 B */
+
+/* One texture = a chain of mip levels of fp32 RGB texels (level 0 = the image,
+ * framework/src/image.cpp:29-32; further levels = 2x2 box filter,
+ * src/main.cpp:745-771).  Offsets count texels in rtx_scene_desc::texels. */
+#define RTX_MAX_MIP_LEVELS 16
+typedef struct rtx_texture {
+    int32_t  levels;
+    int32_t  width[RTX_MAX_MIP_LEVELS];
+    int32_t  height[RTX_MAX_MIP_LEVELS];
+    uint32_t offset[RTX_MAX_MIP_LEVELS];
+} rtx_texture;
+
+/* Lights, src/common.h:44-59.  POINT uses p[0]=position, c[0]=color.
+ * SEGMENT: p[0],p[1]=endpoints, c[0],c[1].  PARALLELOGRAM: p[0]=v0,
+ * p[1]=edge01, p[2]=edge02, c[0..3]. */
+typedef enum rtx_light_type { RTX_LIGHT_POINT = 0, RTX_LIGHT_SEGMENT = 1, RTX_LIGHT_PARALLELOGRAM = 2 } rtx_light_type;
+typedef struct rtx_light {
+    int32_t type;
+    float   p[3][3];
+    float   c[4][3];
+    int32_t pad[2];
+} rtx_light;                 /* 96 B */
+
+/* Sphere, src/common.h:38-42 */
+typedef struct rtx_sphere {
+    float   center[3];
+    float   radius;
+    int32_t material;
+    int32_t pad[3];
+} rtx_sphere;
+
+/* EnvironmentMap, src/environment_mapping.h:9-33 */
+typedef enum rtx_env_type { RTX_ENV_CYLINDRICAL = 0, RTX_ENV_SPHERICAL = 1 } rtx_env_type;
+typedef struct rtx_envmap {
+    int32_t texture;         /* index into textures, -1 = constant background  */
+    int32_t mapping;         /* rtx_env_type                                   */
+    float   vfov_radians;    /* verticalFOVFactor                              */
+    float   background[3];
+} rtx_envmap;
+
+typedef struct rtx_scene_desc {
+    const rtx_node*     nodes;       uint32_t n_nodes;
+    int32_t             root_ref;    /* node index, leaf reference, or INT32_MIN for an empty tree */
+    int32_t             root_cnt;
+    float               root_lo[3], root_hi[3];
+    const rtx_tri*      tris;        /* leaf order                              */
+    const rtx_tri_attr* tri_attrs;   uint32_t n_tris;
+    const rtx_material* materials;   uint32_t n_materials;
+    const rtx_texture*  textures;    uint32_t n_textures;
+    const float*        texels;      uint64_t n_texels;   /* RGB triplets       */
+    const rtx_light*    lights;      uint32_t n_lights;
+    const rtx_sphere*   spheres;     uint32_t n_spheres;
+    rtx_envmap          envmap;
+    int32_t             num_levels;  /* BvhInterface::numLevels                 */
+    int32_t             num_leaves;  /* BvhInterface::numLeaves                 */
+} rtx_scene_desc;
+
+/* ---- camera: Trackball state (framework/src/trackball.cpp:64-110) --------- */
+typedef struct rtx_camera {
+    float look_at[3];
+    float euler[3];          /* radians                                        */
+    float distance;
+    float fovy;              /* radians                                        */
+    float half_width;        /* aspect * tan(fovy/2)                           */
+    float half_height;       /* tan(fovy/2)                                    */
+    float position[3];       /* look_at + quat(euler) * (0,0,-distance)        */
+    float quat[4];           /* w,x,y,z of glm::quat(euler), host libm         */
+} rtx_camera;
+
+/* ---- frame drivers: src/render.h:18-26 ------------------------------------ */
+typedef enum rtx_driver {
+    RTX_DRIVER_PLAIN = 0,         /* renderRayTracing               src/render.cpp:69-90   */
+    RTX_DRIVER_MRAYS = 1,         /* renderRayTracingMRaysPerPixel  src/render.cpp:152-183 */
+    RTX_DRIVER_DOF = 2,           /* renderRayTracingDepthOfField   src/render.cpp:92-126  */
+    RTX_DRIVER_TRANSPARENCY = 3,  /* renderRayTracingTransparency   src/render.cpp:129-150 */
+    RTX_DRIVER_MOTION_BLUR = 4    /* renderRayTracingMotionBlur     src/render.cpp:190-253 (second and later calls) */
+} rtx_driver;
+
+typedef struct rtx_render_params {
+    int32_t  width, height;
+    int32_t  driver;          /* rtx_driver                                     */
+    int32_t  ray_depth;       /* getFinalColor's rayDepth; -1 = the driver's own (1,0,0,1,1) */
+    int32_t  samples;         /* spp / lens samples / blur steps; <=0 = the driver's default (64,100,7) */
+    float    aperture;        /* DoF, default 0.1                               */
+    float    focal_length;    /* DoF, default 2.0                               */
+    int32_t  shadow_samples;  /* sampleSize,   src/light.cpp:14   (50)          */
+    int32_t  glossy_rays;     /* numberOfRays, src/shading.cpp:9  (5)           */
+    uint32_t seed;            /* key of the counter RNG used for light / glossy draws */
+    /* interleaved-tile partition: this call renders tiles t with
+     * t % tile_world == tile_rank; tile_world <= 1 renders the whole frame.   */
+    int32_t  tile_size;       /* square tile edge in pixels, 0 = default (32)   */
+    int32_t  tile_rank, tile_world;
+    rtx_camera prev_camera;   /* motion blur: camera of the previous call       */
+    int32_t  reserved[8];
+} rtx_render_params;
+
+typedef struct rtx_stats {
+    uint64_t rays_primary;    /* BvhInterface::intersect-equivalent queries, by kind */
+    uint64_t rays_shadow;
+    uint64_t rays_bounce;
+    uint64_t box_tests;       /* child boxes tested by the device traversal     */
+    uint64_t tri_tests;       /* triangle records tested by the device traversal*/
+    uint64_t shaded_hits;
+    double   kernel_ms;       /* device time of the render / trace kernel (HIP events) */
+    double   total_ms;        /* wall time of the call                          */
+} rtx_stats;
+
+typedef struct rtx_scene rtx_scene;   /* device-resident scene, reference-counted */
+
+/* Select the GPU this thread uses and create its stream.  Replaces nothing in
+ * the reference (it has no device); must precede every other call. */
+int rtx_init(int device);
+
+/* Upload a flattened scene once.  Replaces the tail of
+ * BvhInterface::BvhInterface (src/bvh_interface.cpp:6-9): the host has built
+ * the tree, this copies it to HBM.  Returns NULL on failure. */
+rtx_scene* rtx_scene_create(const rtx_scene_desc* desc);
+/* BvhInterface is trivially copyable in the reference (src/main.cpp:218
+ * re-assigns it), so handles are reference-counted. */
+void rtx_scene_retain(rtx_scene* scene);
+void rtx_scene_destroy(rtx_scene* scene);
+
+/* Batch form of BvhInterface::intersect (src/bvh_interface.cpp:48-51 ->
+ * src/bounding_volume_hierarchy.cpp:320-458): n closest-hit queries.
+ * rays/hits are host buffers. */
+int rtx_trace(const rtx_scene* scene, const rtx_ray* rays, size_t n, rtx_hit* hits,
+              const rtx_features* features, rtx_stats* stats);
+/* Same, with rays/hits already resident in HBM (device pointers). */
+int rtx_trace_device(const rtx_scene* scene, const rtx_ray* d_rays, size_t n, rtx_hit* d_hits,
+                     const rtx_features* features, rtx_stats* stats);
+
+/* One frame: the five renderRayTracing* drivers (src/render.cpp:69-253) with
+ * getFinalColor (src/render.cpp:16-66) underneath.  out_rgb is a host buffer of
+ * width*height*3 floats in Screen layout, row 0 = top (src/screen.cpp:37-43).
+ * With tile_world > 1 only this rank's tiles are written; the rest is left
+ * untouched. */
+int rtx_render(const rtx_scene* scene, const rtx_camera* camera, const rtx_features* features,
+               const rtx_render_params* params, float* out_rgb, rtx_stats* stats);
+/* Same with the framebuffer in HBM (device pointer); no host copy is made. */
+int rtx_render_device(const rtx_scene* scene, const rtx_camera* camera, const rtx_features* features,
+                      const rtx_render_params* params, float* d_out_rgb, rtx_stats* stats);
+/* Same, but this rank's tiles are written compactly: tile k of this rank
+ * (k-th tile with index % tile_world == tile_rank, row-major tile order) occupies
+ * floats [k*tile_size*tile_size*3, ...) of d_tiles, rows top-down inside the
+ * tile.  This is the buffer the multi-GPU gather moves. */
+int rtx_render_tiles_device(const rtx_scene* scene, const rtx_camera* camera, const rtx_features* features,
+                            const rtx_render_params* params, float* d_tiles, rtx_stats* stats);
+/* Scatter gathered tile buffers (tile_world consecutive buffers of
+ * rtx_tiles_per_rank*tile_size^2*3 floats each, rank-major) into a
+ * Screen-layout frame.  Both pointers are device pointers. */
+int rtx_detile_device(const float* d_all_tiles, const rtx_render_params* params, float* d_out_rgb);
+/* Number of tiles each rank's compact buffer holds (the maximum over ranks). */
+int rtx_tiles_per_rank(const rtx_render_params* params);
+
+/* Block until all work queued by this thread's calls has finished. */
+int rtx_synchronize(void);
+
+/* Text of the most recent failure on the calling thread ("" if none). */
+const char* rtx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

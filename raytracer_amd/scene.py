@@ -1,0 +1,194 @@
+"""Host-side scene container (the reference's Scene, src/scene.h:31-37, as flat
+numpy arrays), its .npz form, the default camera and seeded procedural meshes.
+"""
+import math
+
+import numpy as np
+
+from . import abi
+
+
+class MeshData:
+    """One Mesh (framework/include/framework/mesh.h:36-43): vertices are rows of
+    (position, normal, texCoord), triangles index them, one Material per mesh
+    as (kd, ks, shininess, transparency), and an optional kd texture (h, w, 3)."""
+
+    def __init__(self, vertices, triangles, material, texture=None):
+        self.vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 8)
+        self.triangles = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        self.material = np.ascontiguousarray(material, np.float32).reshape(8)
+        self.texture = None if texture is None else np.ascontiguousarray(texture, np.float32)
+        if self.triangles.size and int(self.triangles.max()) >= len(self.vertices):
+            raise ValueError("triangle index out of range")
+
+
+class SceneData:
+    def __init__(self):
+        self.meshes = []
+        self.lights = []          # abi.Light
+        self.spheres = []         # (center(3), radius, material(8))
+        self.envmap = None        # dict(image=(h,w,3) or None, mapping, vfov_degrees, background)
+
+    @property
+    def n_triangles(self):
+        return sum(len(m.triangles) for m in self.meshes)
+
+    def add_mesh(self, vertices, triangles, material=(1, 1, 1, 0, 0, 0, 1, 1), texture=None):
+        self.meshes.append(MeshData(vertices, triangles, material, texture))
+        return self
+
+    def add_sphere(self, center, radius, material):
+        self.spheres.append((np.asarray(center, np.float32), float(radius), np.asarray(material, np.float32)))
+        return self
+
+    def set_envmap(self, image, mapping=abi.ENV_SPHERICAL, vfov_degrees=180.0, background=(0, 0, 0)):
+        self.envmap = dict(image=None if image is None else np.ascontiguousarray(image, np.float32),
+                           mapping=int(mapping), vfov_degrees=float(vfov_degrees),
+                           background=np.asarray(background, np.float32))
+        return self
+
+    # ---- .npz form (fixtures) ------------------------------------------------
+    def to_arrays(self):
+        d = {"n_meshes": np.int32(len(self.meshes))}
+        for i, m in enumerate(self.meshes):
+            d[f"m{i}_v"], d[f"m{i}_t"], d[f"m{i}_mat"] = m.vertices, m.triangles, m.material
+            if m.texture is not None:
+                d[f"m{i}_tex"] = m.texture
+        lights = np.zeros((len(self.lights), 22), np.float32)
+        for i, l in enumerate(self.lights):
+            lights[i, 0] = l.type
+            lights[i, 1:10] = np.array([list(r) for r in l.p], np.float32).ravel()
+            lights[i, 10:22] = np.array([list(r) for r in l.c], np.float32).ravel()
+        d["lights"] = lights
+        d["spheres"] = np.array([np.concatenate([c, [r], m]) for c, r, m in self.spheres], np.float32).reshape(-1, 12)
+        if self.envmap is not None:
+            e = self.envmap
+            d["env_meta"] = np.array([e["mapping"], e["vfov_degrees"], *e["background"]], np.float32)
+            if e["image"] is not None:
+                d["env_image"] = e["image"]
+        return d
+
+    @staticmethod
+    def from_arrays(d):
+        s = SceneData()
+        for i in range(int(d["n_meshes"])):
+            tex = d[f"m{i}_tex"] if f"m{i}_tex" in d else None
+            s.add_mesh(d[f"m{i}_v"], d[f"m{i}_t"], d[f"m{i}_mat"], tex)
+        for row in d["lights"]:
+            s.lights.append(abi.make_light(int(row[0]), row[1:10].reshape(3, 3), row[10:22].reshape(4, 3)))
+        for row in d["spheres"]:
+            s.add_sphere(row[0:3], row[3], row[4:12])
+        if "env_meta" in d:
+            m = d["env_meta"]
+            s.set_envmap(d["env_image"] if "env_image" in d else None, int(m[0]), float(m[1]), m[2:5])
+        return s
+
+    def save(self, path):
+        np.savez_compressed(path, **self.to_arrays())
+
+    @staticmethod
+    def load(path):
+        with np.load(path) as z:
+            return SceneData.from_arrays({k: z[k] for k in z.files})
+
+
+def make_camera(fov_degrees=50.0, distance=3.0, look_at=(0, 0, 0), rotation_degrees=(20, 20, 0)):
+    """CameraConfig defaults (src/config.h:16-21) converted like src/main.cpp:566-567
+    (glm::radians in fp32).  Derived fields are filled by the host library."""
+    cam = abi.Camera()
+    cam.look_at[:] = [float(x) for x in look_at]
+    cam.euler[:] = [float(np.float32(x) * abi.GLM_RADIANS) for x in rotation_degrees]
+    cam.distance = float(distance)
+    cam.fovy = float(np.float32(fov_degrees) * abi.GLM_RADIANS)
+    return cam
+
+
+def make_params(width, height, driver=abi.DRIVER_PLAIN, **kw):
+    rp = abi.RenderParams()
+    rp.width, rp.height, rp.driver = int(width), int(height), int(driver)
+    rp.ray_depth = -1
+    rp.seed = 1
+    for k, v in kw.items():
+        if k == "prev_camera":
+            rp.prev_camera = v
+        else:
+            if not hasattr(rp, k):
+                raise AttributeError(k)
+            setattr(rp, k, v)
+    return rp
+
+
+# ---- procedural geometry ------------------------------------------------------
+def _vertex_normals(pos, tris):
+    n = np.zeros_like(pos, dtype=np.float64)
+    a, b, c = pos[tris[:, 0]], pos[tris[:, 1]], pos[tris[:, 2]]
+    fn = np.cross(b - a, c - a)
+    for k in range(3):
+        np.add.at(n, tris[:, k], fn)
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    ln[ln == 0] = 1
+    return (n / ln).astype(np.float32)
+
+
+def _normalize_unit(pos):
+    """centerAndScaleToUnitMesh (framework/src/mesh.cpp:151-176) in spirit: centre on
+    the vertex mean and scale the farthest vertex to distance 1."""
+    pos = pos - pos.mean(axis=0, keepdims=True)
+    return (pos / np.linalg.norm(pos, axis=1).max()).astype(np.float32)
+
+
+def icosphere(subdivisions):
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5],
+                  [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], np.int64)
+    for _ in range(subdivisions):
+        edges = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+        uniq, inv = np.unique(edges, axis=0, return_inverse=True)
+        mid = v[uniq[:, 0]] + v[uniq[:, 1]]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        base = len(v)
+        v = np.concatenate([v, mid])
+        n = len(f)
+        ab, bc, ca = base + inv[:n], base + inv[n:2 * n], base + inv[2 * n:]
+        f = np.concatenate([np.stack([f[:, 0], ab, ca], 1), np.stack([f[:, 1], bc, ab], 1),
+                            np.stack([f[:, 2], ca, bc], 1), np.stack([ab, bc, ca], 1)])
+    return v, f
+
+
+def dragon_standin(seed=1, subdivisions=6, material=(0.8, 0.6, 0.4, 0.0, 0.0, 0.0, 1.0, 1.0)):
+    """Seeded stand-in for data/dragon.obj, which is not part of the reference
+    checkout: an icosphere (subdivisions=6 -> 81 920 triangles, the dragon has
+    about 87 K) displaced by a few octaves of seeded sinusoids into a lumpy,
+    self-occluding blob, then normalised to the unit ball like loadMesh(...,
+    normalize=true).  Returns one MeshData."""
+    rng = np.random.default_rng(seed)
+    v, f = icosphere(subdivisions)
+    disp = np.zeros(len(v))
+    for octave in range(5):
+        freq = 1.5 * 2.0 ** octave
+        for _ in range(3):
+            k = rng.normal(size=3)
+            k *= freq / np.linalg.norm(k)
+            disp += (0.28 / 2.0 ** octave) * np.sin(v @ k + rng.uniform(0, 2 * math.pi))
+    pos = v * (1.0 + disp)[:, None]
+    pos[:, 0] *= 1.4
+    pos[:, 1] *= 0.8
+    pos = _normalize_unit(pos)
+    tris = f.astype(np.uint32)
+    nrm = _vertex_normals(pos.astype(np.float64), tris)
+    uv = np.stack([np.arctan2(v[:, 2], v[:, 0]) / (2 * math.pi) + 0.5, np.arccos(np.clip(v[:, 1], -1, 1)) / math.pi], 1)
+    verts = np.concatenate([pos, nrm, uv.astype(np.float32)], axis=1).astype(np.float32)
+    return MeshData(verts, tris, material)
+
+
+def dragon_scene(seed=1, subdivisions=6):
+    """SceneType::Dragon (src/scene.cpp:68-73) with the stand-in mesh: one point
+    light at (-1, 1, -1), white."""
+    s = SceneData()
+    s.meshes.append(dragon_standin(seed, subdivisions))
+    s.lights.append(abi.point_light((-1, 1, -1), (1, 1, 1)))
+    return s
