@@ -1,0 +1,32 @@
+# Builds every native piece in-tree:
+#   raytracer_amd/librtx_hip.so    HIP kernels + C ABI (include/rtx.h), gfx950
+#   raytracer_amd/librtx_host.so   C++ host side: reference-shaped API, BVH builder, flattener
+#   oracle/liboracle.so (+ oracle/_ref/libref.so where /root/reference exists)   test infrastructure
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+ARCH     ?= gfx950
+# -ffp-contract=off: no fused multiply-add on host or device; results must be
+# bit-identical to the reference's plain fp32 arithmetic
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Iraytracer_amd/csrc
+CXXFLAGS ?= -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude -Iraytracer_amd/host
+
+HOST_SRC := $(wildcard raytracer_amd/host/*.cpp)
+HOST_HDR := $(wildcard raytracer_amd/host/*.h) include/rtx.h
+
+.PHONY: all hip host oracle clean
+all: hip host oracle
+
+hip: raytracer_amd/librtx_hip.so
+raytracer_amd/librtx_hip.so: raytracer_amd/csrc/rtx_hip.hip raytracer_amd/csrc/rtx_device.hpp include/rtx.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ raytracer_amd/csrc/rtx_hip.hip
+
+host: raytracer_amd/librtx_host.so
+raytracer_amd/librtx_host.so: $(HOST_SRC) $(HOST_HDR) raytracer_amd/librtx_hip.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -Lraytracer_amd -lrtx_hip -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -f raytracer_amd/librtx_hip.so raytracer_amd/librtx_host.so
+	$(MAKE) -C oracle clean

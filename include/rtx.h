@@ -77,7 +77,8 @@ typedef struct rtx_hit {
  * Built on the host by the reference's builder
  * (src/bounding_volume_hierarchy.cpp:101-180) and flattened to 64-byte records.
  * A child reference r >= 0 is an inner node index; r < 0 is a leaf whose
- * triangles are records [~r, ~r + count) of the leaf-ordered triangle array. */
+ * triangles are records [~r, ~r + count) of the leaf-ordered triangle array
+ * (the last one also carries RTX_TRI_LAST_IN_LEAF). */
 typedef struct rtx_node {
     float   lo0[3], hi0[3];  /* box of child 0 (reference "left")              */
     float   lo1[3], hi1[3];  /* box of child 1 (reference "right")             */
@@ -91,8 +92,9 @@ typedef struct rtx_tri {
     float   d;               /* dot(v0, n)                                     */
     int32_t id;              /* meshTrianglePairs index                        */
     int32_t material;
-    int32_t pad;
+    int32_t flags;           /* bit 0: last triangle of its leaf               */
 } rtx_tri;                   /* 64 B */
+#define RTX_TRI_LAST_IN_LEAF 1
 
 typedef struct rtx_tri_attr {
     float n0[3], n1[3], n2[3];   /* vertex normals                             */
@@ -119,6 +121,7 @@ typedef struct rtx_texture {
     int32_t  width[RTX_MAX_MIP_LEVELS];
     int32_t  height[RTX_MAX_MIP_LEVELS];
     uint32_t offset[RTX_MAX_MIP_LEVELS];
+    uint32_t count[RTX_MAX_MIP_LEVELS];   /* texels stored for the level */
 } rtx_texture;
 
 /* Lights, src/common.h:44-59.  POINT uses p[0]=position, c[0]=color.

@@ -160,6 +160,11 @@ class _Engine:
         self.fn("kat_glossy")(_ptr(r), C.c_float(blur), n_rays, C.c_uint32(seed), C.c_uint32(pixel), _ptr(out))
         return out
 
+    def kat_minstd(self, skip, n, a=0.0, b=1.0):
+        out = np.zeros(n, np.float32)
+        self.fn("kat_minstd")(C.c_uint64(skip), int(n), C.c_float(a), C.c_float(b), _ptr(out))
+        return out
+
     def kat_camera(self, cam, aspect, ndc):
         ndc = np.ascontiguousarray(ndc, np.float32).reshape(-1, 2)
         out = np.zeros(len(ndc), abi.RAY_DTYPE)

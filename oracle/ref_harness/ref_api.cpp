@@ -39,6 +39,7 @@
 
 thread_local uint32_t rtx_shim_seed = 0;
 thread_local uint32_t rtx_shim_pixel = 0;
+thread_local uint32_t rtx_shim_sample = 0;
 thread_local uint32_t rtx_shim_counter = 0;
 
 namespace {
@@ -416,6 +417,7 @@ int ref_render(void* p, void* b, const rtx_camera* cam, const rtx_features* f, c
         for (int y = 0; y < H; y++) {
             for (int x = 0; x != W; x++) {
                 rtx_shim_pixel = uint32_t(y) * uint32_t(W) + uint32_t(x);
+                rtx_shim_sample = 0;
                 rtx_shim_counter = 0;
                 const glm::vec2 ndc { float(x) / float(W) * 2.0f - 1.0f, float(y) / float(H) * 2.0f - 1.0f };
                 glm::vec3 col(0.f);
@@ -425,6 +427,8 @@ int ref_render(void* p, void* b, const rtx_camera* cam, const rtx_features* f, c
                     break;
                 case RTX_DRIVER_MRAYS:
                     for (int i = 0; i < spp; i++) {
+                        rtx_shim_sample = uint32_t(i);
+                        rtx_shim_counter = 0;
                         const glm::vec2 q { float(x + dist01(rng)) / float(W) * 2.0f - 1.0f, float(y + dist01(rng)) / float(H) * 2.0f - 1.0f };
                         col += getFinalColor(s->scene, *bvh, camera.generateRay(q), feat, depth);
                     }
@@ -434,8 +438,12 @@ int ref_render(void* p, void* b, const rtx_camera* cam, const rtx_features* f, c
                     Ray cr = camera.generateRay(ndc);
                     glm::vec3 fp = getFocalPoint(cr, focal);
                     std::vector<Ray> rays = sampledRays(fp, generateSamples(cr.origin, aperture, spp, rng, distAp));
-                    for (auto r : rays)
+                    uint32_t si = 0;
+                    for (auto r : rays) {
+                        rtx_shim_sample = si++;
+                        rtx_shim_counter = 0;
                         col += getFinalColor(s->scene, *bvh, r, feat, depth);
+                    }
                     col = col * glm::vec3(1.0f / (rays.size()));
                 } break;
                 case RTX_DRIVER_TRANSPARENCY: {
@@ -567,6 +575,7 @@ void ref_kat_light_samples(const rtx_light* l, uint32_t seed, uint32_t pixel, in
 {
     rtx_shim_seed = seed;
     rtx_shim_pixel = pixel;
+    rtx_shim_sample = 0;
     rtx_shim_counter = 0;
     for (int i = 0; i < n; i++) {
         glm::vec3 pp, cc;
@@ -583,6 +592,7 @@ void ref_kat_glossy(const rtx_ray* reflection, float degreeBlur, int nRays, uint
 {
     rtx_shim_seed = seed;
     rtx_shim_pixel = pixel;
+    rtx_shim_sample = 0;
     rtx_shim_counter = 0;
     numberOfRays = nRays;
     Ray r { v3(reflection->origin), v3(reflection->direction), reflection->t };
@@ -604,6 +614,18 @@ void ref_kat_camera(const rtx_camera* cam, float fovy, float aspect, const float
         put3(out[i].direction, r.direction);
         out[i].t = r.t;
     }
+}
+
+// draws of std::default_random_engine through std::uniform_real_distribution<float>(a, b)
+// after `skip` discarded draws: the stream the reference's single-thread drivers consume
+void ref_kat_minstd(uint64_t skip, int n, float a, float b, float* out)
+{
+    std::default_random_engine rng;
+    std::uniform_real_distribution<float> dist(a, b);
+    for (uint64_t i = 0; i < skip; i++)
+        (void)dist(rng);
+    for (int i = 0; i < n; i++)
+        out[i] = dist(rng);
 }
 
 } // extern "C"

@@ -161,7 +161,7 @@ Feat toFeat(const rtx_features* f)
 // --------------------------------------------------------- keyed uniforms ----
 // One uniform per std::random_device construction of the reference
 // (src/light.cpp:16-23, src/shading.cpp:56-65), as a pure function of
-// (seed, pixel, draw index).  Value = float(bits) / 2^32 clamped below 1, which
+// (seed, pixel, sample, draw index).  Value = float(bits) / 2^32 clamped below 1, which
 // is what std::uniform_real_distribution<float>(0,1) makes of a 32-bit engine.
 inline uint32_t mix32(uint32_t x)
 {
@@ -172,18 +172,28 @@ inline uint32_t mix32(uint32_t x)
     x ^= x >> 16;
     return x;
 }
-inline float keyedUniform(uint32_t seed, uint32_t pixel, uint32_t counter)
+inline uint32_t sampleKey(uint32_t seed, uint32_t pixel, uint32_t sample)
 {
     const uint32_t h = mix32(seed ^ (pixel * 0x9e3779b1u));
-    const uint32_t bits = mix32(h ^ (counter * 0x85ebca77u) ^ 0x68bc21ebu);
+    return mix32(h ^ (sample * 0xc2b2ae35u) ^ 0x27d4eb2fu);
+}
+inline float keyedUniform(uint32_t key, uint32_t counter)
+{
+    const uint32_t bits = mix32(key ^ (counter * 0x85ebca77u) ^ 0x68bc21ebu);
     float u = float(bits) / 4294967296.0f;
     if (u >= 1.0f)
         u = 0.99999994f;
     return u;
 }
+// draws of one camera sample, numbered in the reference's depth-first order
 struct PixelRng {
-    uint32_t seed = 0, pixel = 0, counter = 0;
-    float next() { return keyedUniform(seed, pixel, counter++); }
+    uint32_t seed = 0, key = 0, counter = 0;
+    void start(uint32_t pixel, uint32_t sample)
+    {
+        key = sampleKey(seed, pixel, sample);
+        counter = 0;
+    }
+    float next() { return keyedUniform(key, counter++); }
 };
 
 // std::default_random_engine = minstd_rand0 (x <- 16807 x mod 2^31-1, seed 1),
@@ -947,8 +957,7 @@ V3 renderPixel(Ctx& cx, const Camera& cam, const Camera& prev, const rtx_render_
     const int depth = rp.ray_depth >= 0 ? rp.ray_depth : defaultDepth(driver);
     const int n = rp.samples > 0 ? rp.samples : (driver == RTX_DRIVER_MRAYS ? 64 : driver == RTX_DRIVER_DOF ? 100 : 7);
     const uint64_t pixelIndex = uint64_t(y) * uint64_t(W) + uint64_t(x);
-    cx.rng.pixel = uint32_t(pixelIndex);
-    cx.rng.counter = 0;
+    cx.rng.start(uint32_t(pixelIndex), 0);
     const float ndcX = float(x) / float(W) * 2.0f - 1.0f, ndcY = float(y) / float(H) * 2.0f - 1.0f;
     switch (driver) {
     case RTX_DRIVER_PLAIN:
@@ -959,6 +968,7 @@ V3 renderPixel(Ctx& cx, const Camera& cam, const Camera& prev, const rtx_render_
         Minstd rng = Minstd::at(pixelIndex * 2ull * uint64_t(n));
         V3 col = mk(0, 0, 0);
         for (int i = 0; i < n; i++) {
+            cx.rng.start(uint32_t(pixelIndex), uint32_t(i));
             const float jx = rng.uniform(0.f, 1.f);
             const float jy = rng.uniform(0.f, 1.f);
             const float qx = float(float(x) + jx) / float(W) * 2.0f - 1.0f;
@@ -983,7 +993,9 @@ V3 renderPixel(Ctx& cx, const Camera& cam, const Camera& prev, const rtx_render_
             origins.push_back(cr.o + mk(sx, sy, sz));
         }
         V3 col = mk(0, 0, 0);
+        uint32_t si = 0;
         for (const V3& o : origins) {
+            cx.rng.start(uint32_t(pixelIndex), si++);
             Ray r;
             r.o = o;
             r.d = normalize(focalPoint - o);
@@ -1000,6 +1012,7 @@ V3 renderPixel(Ctx& cx, const Camera& cam, const Camera& prev, const rtx_render_
         const float scaleDistance = cam.dist - prev.dist;
         V3 col = mk(0, 0, 0);
         for (int i = 0; i < n; i++) {
+            cx.rng.start(uint32_t(pixelIndex), uint32_t(i));
             const float jitter = rng.uniform(0.f, 1.f);
             const float lerp = jitter + float(i);
             const float w = lerp / float(n);
@@ -1294,7 +1307,9 @@ void orc_kat_envmap(const float* rgb, int w, int h, int mapping, float vfovDegre
 }
 void orc_kat_light_samples(const rtx_light* l, uint32_t seed, uint32_t pixel, int n, float* pos, float* col)
 {
-    PixelRng rng { seed, pixel, 0 };
+    PixelRng rng;
+    rng.seed = seed;
+    rng.start(pixel, 0);
     for (int i = 0; i < n; i++) {
         V3 pp, cc;
         if (l->type == RTX_LIGHT_SEGMENT) {
@@ -1317,7 +1332,9 @@ void orc_kat_light_samples(const rtx_light* l, uint32_t seed, uint32_t pixel, in
 void orc_kat_glossy(const rtx_ray* reflection, float degreeBlur, int nRays, uint32_t seed, uint32_t pixel, rtx_ray* out)
 {
     Scene s;
-    Ctx cx { s, Feat {}, 50, nRays, PixelRng { seed, pixel, 0 }, Counters {} };
+    Ctx cx { s, Feat {}, 50, nRays, PixelRng {}, Counters {} };
+    cx.rng.seed = seed;
+    cx.rng.start(pixel, 0);
     Ray r;
     r.o = mk(reflection->origin);
     r.d = mk(reflection->direction);

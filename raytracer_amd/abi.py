@@ -59,7 +59,7 @@ class EnvMap(C.Structure):
 
 class Texture(C.Structure):
     _fields_ = [("levels", i32), ("width", i32 * RTX_MAX_MIP_LEVELS), ("height", i32 * RTX_MAX_MIP_LEVELS),
-                ("offset", u32 * RTX_MAX_MIP_LEVELS)]
+                ("offset", u32 * RTX_MAX_MIP_LEVELS), ("count", u32 * RTX_MAX_MIP_LEVELS)]
 
 
 class SceneDesc(C.Structure):
@@ -80,7 +80,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("tri", "<i4"), ("normal", "<f4", 3), ("bary
 NODE_DTYPE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3),
                        ("ref0", "<i4"), ("ref1", "<i4"), ("cnt0", "<i4"), ("cnt1", "<i4")])
 TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3), ("n", "<f4", 3), ("d", "<f4"),
-                      ("id", "<i4"), ("material", "<i4"), ("pad", "<i4")])
+                      ("id", "<i4"), ("material", "<i4"), ("flags", "<i4")])
 TRI_ATTR_DTYPE = np.dtype([("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
                            ("uv0", "<f4", 2), ("uv1", "<f4", 2), ("uv2", "<f4", 2), ("pad", "<f4")])
 MATERIAL_DTYPE = np.dtype([("kd", "<f4", 3), ("ks", "<f4", 3), ("shininess", "<f4"), ("transparency", "<f4"),

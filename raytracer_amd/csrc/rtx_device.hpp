@@ -1,0 +1,603 @@
+// Device-side building blocks of the gfx950 ray tracer: fp32 vector algebra in
+// the reference's operation order, ray/box and ray/triangle tests, closest-hit
+// traversal with a per-lane LDS stack, hit attributes, textures, environment
+// map, Phong shading and the samplers.  Compiled with -ffp-contract=off: no
+// fused multiply-add anywhere, so every value that feeds a comparison is
+// bit-identical to the CPU path's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtx.h"
+
+namespace rtxd {
+
+#define RTX_DEV __device__ __forceinline__
+
+constexpr float kFltMax = 3.402823466e+38f;
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------ vec3 ----
+// glm 0.9.9.9 scalar semantics (glm/detail/func_geometric.inl:48-90):
+// dot = (x*x' + y*y') + z*z', normalize(v) = v * (1 / sqrt(dot(v, v))).
+struct V3 {
+    float x, y, z;
+};
+RTX_DEV V3 mk(float x, float y, float z) { return V3 { x, y, z }; }
+RTX_DEV V3 mk(const float* p) { return V3 { p[0], p[1], p[2] }; }
+RTX_DEV V3 operator+(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+RTX_DEV V3 operator-(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+RTX_DEV V3 operator-(V3 a) { return { -a.x, -a.y, -a.z }; }
+RTX_DEV V3 operator*(V3 a, V3 b) { return { a.x * b.x, a.y * b.y, a.z * b.z }; }
+RTX_DEV V3 operator*(V3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+RTX_DEV V3 operator*(float s, V3 a) { return { s * a.x, s * a.y, s * a.z }; }
+RTX_DEV V3 operator/(V3 a, float s) { return { a.x / s, a.y / s, a.z / s }; }
+RTX_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RTX_DEV V3 cross(V3 x, V3 y) { return { x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y }; }
+RTX_DEV float length(V3 v) { return __builtin_sqrtf(dot(v, v)); }
+RTX_DEV V3 normalize(V3 v) { return v * (1.0f / __builtin_sqrtf(dot(v, v))); }
+RTX_DEV float distance(V3 p0, V3 p1) { return length(p1 - p0); }
+
+struct Ray {
+    V3 o, d;
+    float t;
+};
+
+// --------------------------------------------------------- device scene -----
+struct DScene {
+    const float4* nodes;     // 4 x float4 per rtx_node
+    const float4* tris;      // 4 x float4 per rtx_tri (leaf order)
+    const float4* attrs;     // 4 x float4 per rtx_tri_attr
+    const int32_t* idOrder;  // leaf-order record index of triangle id i (brute-force path)
+    const rtx_material* mats;
+    const rtx_texture* textures;
+    const float* texels;
+    const rtx_light* lights;
+    const rtx_sphere* spheres;
+    rtx_envmap env;
+    int32_t nTris, nLights, nSpheres, nMaterials;
+    int32_t rootRef;
+    float rootLo[3], rootHi[3];
+};
+
+constexpr int32_t kEmptyRoot = INT32_MIN;
+
+// ------------------------------------------------------------ primitives ----
+// Ray/box slab test, src/intersect.cpp:129-158.  Comparisons are written as
+// compare+select (never fmin/fmax) so an axis-parallel ray's NaN (0 * inf)
+// leaves `first`/`second` untouched exactly as in the reference.  Returns
+// whether the box is entered before `tmax`; `key` is the entry distance, or the
+// exit distance when the entry is not in front of the origin.
+RTX_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float& key)
+{
+    float first = 0.0f, second = __builtin_inff();
+    bool fail = false;
+    {
+        float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
+        const bool sw = t0 > t1;
+        const float a = sw ? t1 : t0, b = sw ? t0 : t1;
+        fail |= (a > second) || (b < first);
+        first = (a > first) ? a : first;
+        second = (b < second) ? b : second;
+    }
+    {
+        float t0 = (lo.y - o.y) * inv.y, t1 = (hi.y - o.y) * inv.y;
+        const bool sw = t0 > t1;
+        const float a = sw ? t1 : t0, b = sw ? t0 : t1;
+        fail |= (a > second) || (b < first);
+        first = (a > first) ? a : first;
+        second = (b < second) ? b : second;
+    }
+    {
+        float t0 = (lo.z - o.z) * inv.z, t1 = (hi.z - o.z) * inv.z;
+        const bool sw = t0 > t1;
+        const float a = sw ? t1 : t0, b = sw ? t0 : t1;
+        fail |= (a > second) || (b < first);
+        first = (a > first) ? a : first;
+        second = (b < second) ? b : second;
+    }
+    if (first <= 0.0f)
+        first = second;
+    key = first;
+    return !fail && !(tmax < first);
+}
+
+// src/bounding_volume_hierarchy.cpp:297-307
+RTX_DEV bool inBox(V3 lo, V3 hi, V3 x)
+{
+    return lo.x <= x.x && x.x <= hi.x && lo.y <= x.y && x.y <= hi.y && lo.z <= x.z && x.z <= hi.z;
+}
+
+// Child visit rule of the reference's traversal
+// (src/bounding_volume_hierarchy.cpp:412-439): a child containing the origin is
+// always visited with key 0, otherwise the slab test decides.
+RTX_DEV bool childTest(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float& key)
+{
+    float k;
+    const bool s = slab(lo, hi, o, inv, tmax, k);
+    const bool in = inBox(lo, hi, o);
+    key = in ? 0.0f : k;
+    return in || s;
+}
+
+// Ray/triangle, src/intersect.cpp:32-89, with the plane (n, D) precomputed on
+// the host by the same arithmetic (src/intersect.cpp:50-58).  A degenerate
+// triangle carries NaN in n and D, which fails `t < tmax` below just as the
+// reference's explicit degeneracy test rejects it.
+RTX_DEV bool triangleTest(V3 v0, V3 v1, V3 v2, V3 n, float D, V3 o, V3 d, float tmax, float& tOut)
+{
+    const float dn = dot(n, d);
+    if (dn == 0.f)
+        return false;
+    const float t = (D - dot(n, o)) / dn;
+    if (t <= 0.f || !(t < tmax))
+        return false;
+    const V3 p = o + t * d;
+    const float alpha = dot(n, cross(v2 - v1, p - v1));
+    const float beta = dot(n, cross(p - v0, v2 - v0));
+    const float gamma = dot(n, cross(v1 - v0, p - v0));
+    if (alpha < 0 || beta < 0 || gamma < 0)
+        return false;
+    tOut = t;
+    return true;
+}
+
+// src/intersect.cpp:93-124.  The roots are evaluated in double and rounded to
+// float once, as the reference's unqualified sqrt() call does.
+RTX_DEV bool sphereTest(const rtx_sphere& s, V3 o, V3 d, float& t, V3& normal)
+{
+    const V3 c = mk(s.center);
+    const float a = dot(d, d);
+    const float b = 2 * dot(d, o - c);
+    const float cc = dot(c, c) + dot(o, o) - 2 * dot(o, c) - s.radius * s.radius;
+    const float delta = b * b - 4 * a * cc;
+    if (delta < 0)
+        return false;
+    const double sq = __builtin_sqrt(double(delta));
+    const float t1 = float((double(-b) + sq) / double(2 * a));
+    const float t2 = float((double(-b) - sq) / double(2 * a));
+    if (t2 < 0) {
+        if (t > t2)
+            t = (t < t1) ? t : t1; // std::min(t1, ray.t)
+        else
+            return false;
+    } else {
+        if (t1 > 0.f && t > t1)
+            t = (t < t2) ? t : t2;
+        else
+            return false;
+    }
+    const V3 p = o + t * d;
+    normal = normalize(p - c);
+    return true;
+}
+
+struct TriRec {
+    V3 v0, v1, v2, n;
+    float d;
+    int32_t id, material, flags;
+};
+RTX_DEV TriRec loadTri(const DScene& sc, int k)
+{
+    const float4* p = sc.tris + size_t(k) * 4;
+    const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+    TriRec r;
+    r.v0 = mk(a.x, a.y, a.z);
+    r.v1 = mk(a.w, b.x, b.y);
+    r.v2 = mk(b.z, b.w, c.x);
+    r.n = mk(c.y, c.z, c.w);
+    r.d = e.x;
+    r.id = __float_as_int(e.y);
+    r.material = __float_as_int(e.z);
+    r.flags = __float_as_int(e.w);
+    return r;
+}
+
+// --------------------------------------------------------------- traversal --
+// Per-lane traversal stack in LDS: entry e of lane l lives at stack[e][l], so a
+// wave's 64 lanes always touch 64 different banks whatever their stack depths.
+template <int STACK>
+struct LaneStack {
+    int32_t* refs;  // [STACK][kBlock]
+    float* keys;    // [STACK][kBlock]
+    int tid;
+    RTX_DEV void push(int sp, int32_t ref, float key)
+    {
+        refs[sp * kBlock + tid] = ref;
+        keys[sp * kBlock + tid] = key;
+    }
+    RTX_DEV void pop(int sp, int32_t& ref, float& key)
+    {
+        ref = refs[sp * kBlock + tid];
+        key = keys[sp * kBlock + tid];
+    }
+};
+
+struct TraceCounters {
+    uint32_t boxTests, triTests;
+};
+
+// Closest hit of one ray (BoundingVolumeHierarchy::intersect,
+// src/bounding_volume_hierarchy.cpp:320-458) without the spheres.  The
+// reference visits nodes best-first from a priority queue; this walks the same
+// tree depth-first, nearer child first, with the same visit predicates: a
+// child is entered only if `t >= key` held when it was tested and still holds
+// when it is popped.  The closest hit is the same except when two candidates
+// are within rounding of each other (exact-t ties keep the first one tested,
+// and the test order differs).
+// On return t is the closest distance (unchanged on a miss) and bestK the
+// leaf-order record index of the hit triangle (-1 on a miss).
+template <int STACK, bool COUNT>
+RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, float& t, int& bestK, TraceCounters& tc)
+{
+    bestK = -1;
+    if (sc.rootRef == kEmptyRoot)
+        return;
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    {
+        float key;
+        if (COUNT)
+            tc.boxTests++;
+        if (!slab(mk(sc.rootLo), mk(sc.rootHi), o, inv, t, key))
+            return;
+    }
+    int sp = 0;
+    int32_t cur = sc.rootRef;
+    bool have = true;
+    while (have) {
+        if (cur >= 0) {
+            const float4* np = sc.nodes + size_t(cur) * 4;
+            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+            float k0, k1;
+            if (COUNT)
+                tc.boxTests += 2;
+            const bool h0 = childTest(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), o, inv, t, k0);
+            const bool h1 = childTest(mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), o, inv, t, k1);
+            const int32_t r0 = __float_as_int(e.x), r1 = __float_as_int(e.y);
+            if (h0 && h1) {
+                const bool firstIs1 = k1 < k0;
+                st.push(sp++, firstIs1 ? r0 : r1, firstIs1 ? k0 : k1);
+                cur = firstIs1 ? r1 : r0;
+                continue;
+            } else if (h0) {
+                cur = r0;
+                continue;
+            } else if (h1) {
+                cur = r1;
+                continue;
+            }
+        } else {
+            int k = ~cur;
+            for (;;) {
+                const TriRec tr = loadTri(sc, k);
+                if (COUNT)
+                    tc.triTests++;
+                float th;
+                if (triangleTest(tr.v0, tr.v1, tr.v2, tr.n, tr.d, o, d, t, th)) {
+                    t = th;
+                    bestK = k;
+                }
+                if (tr.flags & RTX_TRI_LAST_IN_LEAF)
+                    break;
+                k++;
+            }
+        }
+        // pop the next node that is still worth visiting
+        have = false;
+        while (sp > 0) {
+            float key;
+            st.pop(--sp, cur, key);
+            if (!(t < key)) {
+                have = true;
+                break;
+            }
+        }
+    }
+}
+
+// Brute-force path (features.enableAccelStructure == false),
+// src/bounding_volume_hierarchy.cpp:330-360: every triangle in scene order,
+// with the extra `t > 1e-6` acceptance rule.
+template <bool COUNT>
+RTX_DEV void traverseAll(const DScene& sc, V3 o, V3 d, float& t, int& bestK, TraceCounters& tc)
+{
+    bestK = -1;
+    for (int i = 0; i < sc.nTris; i++) {
+        const int k = sc.idOrder[i];
+        const TriRec tr = loadTri(sc, k);
+        if (COUNT)
+            tc.triTests++;
+        float th;
+        if (triangleTest(tr.v0, tr.v1, tr.v2, tr.n, tr.d, o, d, t, th) && double(th) > 1e-6) {
+            t = th;
+            bestK = k;
+        }
+    }
+}
+
+// HitInfo as the hot path uses it
+struct Hit {
+    V3 normal;
+    float u, v;
+    int32_t k;         // leaf-order record of the triangle, -1 = sphere
+    int32_t material;
+    int32_t id;        // meshTrianglePairs index, or -2 - sphere
+    V3 bary;
+};
+
+// One BvhInterface::intersect: spheres first (src/bounding_volume_hierarchy.cpp:327-328),
+// then triangles, then the winner's attributes (src/bounding_volume_hierarchy.cpp:277-295,
+// src/interpolate.cpp:4-23).
+template <int STACK, bool COUNT>
+RTX_DEV bool intersectScene(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, V3 o, V3 d, float& t, Hit& hit, TraceCounters& tc)
+{
+    bool any = false;
+    hit.k = -1;
+    hit.material = -1;
+    hit.id = RTX_TRI_NONE;
+    hit.normal = mk(0, 0, 0);
+    hit.bary = mk(0, 0, 0);
+    hit.u = hit.v = 0.f;
+    for (int i = 0; i < sc.nSpheres; i++) {
+        V3 n;
+        if (sphereTest(sc.spheres[i], o, d, t, n)) {
+            any = true;
+            hit.normal = n;
+            hit.material = sc.spheres[i].material;
+            hit.id = -2 - i;
+        }
+    }
+    int bestK;
+    if (f.enable_accel_structure)
+        traverseBvh<STACK, COUNT>(sc, st, o, d, t, bestK, tc);
+    else
+        traverseAll<COUNT>(sc, o, d, t, bestK, tc);
+    if (bestK >= 0) {
+        any = true;
+        const TriRec tr = loadTri(sc, bestK);
+        const float4* ap = sc.attrs + size_t(bestK) * 4;
+        const float4 a = ap[0], b = ap[1], c = ap[2], e = ap[3];
+        const V3 n0 = mk(a.x, a.y, a.z), n1 = mk(a.w, b.x, b.y), n2 = mk(b.z, b.w, c.x);
+        const V3 p = o + t * d;
+        // src/interpolate.cpp:4-12: area ratios from lengths
+        const float tArea = length(cross(tr.v1 - tr.v2, tr.v2 - tr.v0));
+        const float ba = length(cross(tr.v1 - p, tr.v2 - p)) / tArea;
+        const float bb = length(cross(tr.v0 - p, tr.v2 - p)) / tArea;
+        const float bg = length(cross(tr.v1 - p, tr.v0 - p)) / tArea;
+        hit.bary = mk(ba, bb, bg);
+        hit.normal = f.enable_normal_interp ? (ba * n0 + bb * n1 + bg * n2) : n0;
+        hit.u = ba * c.y + bb * c.w + bg * e.y;
+        hit.v = ba * c.z + bb * e.x + bg * e.z;
+        hit.k = bestK;
+        hit.material = tr.material;
+        hit.id = tr.id;
+    }
+    return any;
+}
+
+// -------------------------------------------------------------- textures ----
+RTX_DEV V3 texelAt(const DScene& sc, const rtx_texture& tx, int level, uint32_t idx)
+{
+    // the reference reads past the end of a level for odd sizes (undefined
+    // there); such reads return 0 here
+    if (idx >= tx.count[level])
+        return mk(0, 0, 0);
+    const float* p = sc.texels + (size_t(tx.offset[level]) + idx) * 3;
+    return mk(p[0], p[1], p[2]);
+}
+// src/texture.cpp:6-16
+RTX_DEV V3 texelNearest(const DScene& sc, const rtx_texture& tx, float u, float v)
+{
+    const int W = tx.width[0], H = tx.height[0];
+    int i = int(float(W) * u);
+    int j = int(float(H) * (1 - v));
+    i = max(0, min(W - 1, i));
+    j = max(0, min(H - 1, j));
+    return texelAt(sc, tx, 0, uint32_t(j * W + i));
+}
+RTX_DEV float modGlm(float a, float b) { return a - b * __builtin_floorf(a / b); }
+// src/texture.cpp:18-33, src/shading.cpp:174-190
+RTX_DEV V3 texelBilinear(const DScene& sc, const rtx_texture& tx, int level, float tu, float tv)
+{
+    const int W = tx.width[level], H = tx.height[level];
+    const float txp = float(W - 1) * tu, typ = float(H - 1) * (1 - tv);
+    float lx = __builtin_floorf(float(W - 1) * tu), ly = __builtin_floorf(float(H - 1) * (1 - tv));
+    float ux = lx + 1, uy = ly + 1;
+    const float u = txp - lx, v = typ - ly;
+    lx = modGlm(lx, float(W));
+    ly = modGlm(ly, float(H));
+    ux = modGlm(ux, float(W));
+    uy = modGlm(uy, float(H));
+    // float -> size_t conversions of the reference; negative / NaN indices are
+    // undefined there and clamp to "out of range" here
+    const V3 lowerLeft = texelAt(sc, tx, level, uint32_t(ly * float(W) + lx));
+    const V3 upperRight = texelAt(sc, tx, level, uint32_t(uy * float(W) + ux));
+    const V3 lowerRight = texelAt(sc, tx, level, uint32_t(uy * float(W) + lx));
+    const V3 upperLeft = texelAt(sc, tx, level, uint32_t(ly * float(W) + ux));
+    return lowerLeft * (1.0f - u) * (1.0f - v) + upperRight * u * v + lowerRight * (1.0f - u) * v + upperLeft * u * (1.0f - v);
+}
+// src/shading.cpp:107-114
+RTX_DEV V3 planeCoord(V3 ro, V3 rd, V3 point)
+{
+    const V3 w = normalize(rd);
+    const V3 t = normalize(w - mk(0.1f, 0.0f, 0.0f));
+    const V3 x = normalize(cross(t, w));
+    const V3 y = normalize(cross(w, x));
+    const V3 rToP = point - ro;
+    return ro + dot(rToP, x) * x + dot(rToP, y) * y;
+}
+// src/shading.cpp:117-172: level of detail from the ratio of the triangle's
+// area to its area projected on the plane perpendicular to the ray
+RTX_DEV V3 texelTrilinear(const DScene& sc, const rtx_texture& tx, V3 ro, V3 rd, const Hit& hit)
+{
+    if (hit.k < 0)
+        return texelBilinear(sc, tx, 0, hit.u, hit.v);
+    const TriRec tr = loadTri(sc, hit.k);
+    const V3 p0 = planeCoord(ro, rd, tr.v0), p1 = planeCoord(ro, rd, tr.v1), p2 = planeCoord(ro, rd, tr.v2);
+    const float areaV = length(cross(tr.v0 - tr.v1, tr.v0 - tr.v2));
+    const float areaP = length(cross(p0 - p1, p0 - p2));
+    const int levels = tx.levels;
+    float k = float(levels);
+    if (double(areaP) >= 1e-6)
+        k = (areaV / areaP - 1.0f) / 2.8f;
+    const float k0 = __builtin_floorf(k);
+    const float k1 = k0 + 1;
+    const float a = k1 - k;
+    if (k0 < 0)
+        return texelBilinear(sc, tx, 0, hit.u, hit.v);
+    if (k1 >= float(levels))
+        return texelBilinear(sc, tx, levels - 1, hit.u, hit.v);
+    const V3 c0 = texelBilinear(sc, tx, int(k0), hit.u, hit.v);
+    const V3 c1 = texelBilinear(sc, tx, int(k1), hit.u, hit.v);
+    return a * c0 + (1 - a) * c1;
+}
+
+// src/environment_mapping.cpp:167-207; the uv arithmetic is double there
+RTX_DEV V3 envColor(const DScene& sc, const rtx_features& f, V3 d)
+{
+    const V3 bg = mk(sc.env.background);
+    if (sc.env.texture < 0)
+        return bg;
+    const rtx_texture& tx = sc.textures[sc.env.texture];
+    const double kPi = 3.14159265358979323846;
+    const float x = float(double(atan2f(d.z, d.x)) / (2 * kPi) + 0.5);
+    const float cosUp = dot(normalize(d), mk(0.f, 1.f, 0.f));
+    float y;
+    if (sc.env.mapping == RTX_ENV_SPHERICAL)
+        y = float(-(kPi / double(sc.env.vfov_radians)) * (double(acosf(cosUp)) / kPi - 0.5) + 0.5);
+    else
+        y = float(0.5 / double(tanf(0.5f * sc.env.vfov_radians)) / double(tanf(acosf(cosUp))) + 0.5);
+    if (fabs(double(y) - 0.5) > 0.5)
+        return bg;
+    if (f.enable_bilinear_texture_filtering)
+        return texelBilinear(sc, tx, 0, x, y);
+    return texelNearest(sc, tx, x, y);
+}
+
+// --------------------------------------------------------------- shading ----
+// src/shading.cpp:90-96 (direction only; the origin is point + 1e-5 * r)
+RTX_DEV V3 reflectDir(V3 d, V3 normal)
+{
+    return normalize(d) - 2 * dot(normalize(normal), normalize(d)) * normalize(normal);
+}
+
+// src/shading.cpp:13-54.  `albedo` is kd or the texture lookup, already chosen.
+RTX_DEV V3 phong(V3 lightPos, V3 lightColor, V3 position, V3 rayDir, V3 normal, V3 albedo, V3 ks, float shininess)
+{
+    const V3 lightDir = normalize(lightPos - position);
+    const float ndl = dot(normalize(normal), lightDir);
+    if (ndl < 0.0f)
+        return mk(0, 0, 0);
+    const V3 r = reflectDir(lightDir, normal);
+    const float d = fabsf(dot(normalize(r), normalize(rayDir)));
+    const V3 specular = lightColor * ks * powf(d, shininess);
+    return lightColor * albedo * ndl + specular;
+}
+
+// diffuse colour of a hit: kd, or the texture with the reference's filter choice
+// (src/shading.cpp:26-32)
+RTX_DEV V3 albedoOf(const DScene& sc, const rtx_features& f, const rtx_material& m, V3 ro, V3 rd, const Hit& hit)
+{
+    if (m.texture >= 0 && f.enable_texture_mapping) {
+        const rtx_texture& tx = sc.textures[m.texture];
+        if (f.enable_bilinear_texture_filtering) {
+            if (f.enable_mipmap_texture_filtering)
+                return texelTrilinear(sc, tx, ro, rd, hit);
+            return texelBilinear(sc, tx, 0, hit.u, hit.v);
+        }
+        return texelNearest(sc, tx, hit.u, hit.v);
+    }
+    return mk(m.kd);
+}
+
+// ------------------------------------------------------------------- RNG ----
+// Keyed uniforms for light and glossy sampling: draw number `counter` of sample
+// `sample` of pixel `pixel` is a pure function of its key, so any execution
+// order gives the same image.  The value is float(bits) / 2^32 clamped below 1,
+// which is what std::uniform_real_distribution<float>(0,1) makes of one output
+// of a 32-bit engine.
+RTX_DEV uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+RTX_DEV uint32_t sampleKey(uint32_t seed, uint32_t pixel, uint32_t sample)
+{
+    const uint32_t h = mix32(seed ^ (pixel * 0x9e3779b1u));
+    return mix32(h ^ (sample * 0xc2b2ae35u) ^ 0x27d4eb2fu);
+}
+RTX_DEV float keyedUniform(uint32_t key, uint32_t counter)
+{
+    const uint32_t bits = mix32(key ^ (counter * 0x85ebca77u) ^ 0x68bc21ebu);
+    float u = float(bits) * 2.3283064365386963e-10f; // exact: / 2^32
+    if (u >= 1.0f)
+        u = 0.99999994f;
+    return u;
+}
+
+// std::default_random_engine (minstd_rand0: x <- 16807 x mod 2^31-1, seed 1) as
+// the reference's single-thread drivers consume it (src/render.cpp:101-102,
+// 160-161,219-220): one sequential stream over all pixels.  16807^k mod
+// (2^31-1) gives the state after k draws, so each sample finds its own place in
+// that stream.
+constexpr uint64_t kMinstdM = 2147483647ull;
+RTX_DEV uint64_t mulMod(uint64_t a, uint64_t b)
+{
+    uint64_t z = a * b; // < 2^62
+    z = (z & kMinstdM) + (z >> 31);
+    z = (z & kMinstdM) + (z >> 31);
+    return z >= kMinstdM ? z - kMinstdM : z;
+}
+RTX_DEV uint64_t minstdAt(uint64_t draws)
+{
+    uint64_t r = 1, b = 16807;
+    while (draws) {
+        if (draws & 1)
+            r = mulMod(r, b);
+        b = mulMod(b, b);
+        draws >>= 1;
+    }
+    return r;
+}
+// uniform_real_distribution<float>(a, b) of libstdc++ over one minstd output
+RTX_DEV float minstdUniform(uint64_t& x, float a, float b)
+{
+    x = mulMod(x, 16807ull);
+    float c = float(uint32_t(x - 1)) / 2147483648.0f;
+    if (c >= 1.0f)
+        c = 0.99999994f;
+    return c * (b - a) + a;
+}
+
+// ---------------------------------------------------------------- camera ----
+// quat * vec3, glm/detail/type_quat.inl:347-354
+RTX_DEV V3 rotate(float qw, V3 qv, V3 v)
+{
+    const V3 uv = cross(qv, v);
+    const V3 uuv = cross(qv, uv);
+    return v + ((uv * qw) + uuv) * 2.0f;
+}
+// glm::quat(euler), glm/detail/type_quat.inl:208-217 (device trig: used only by
+// the motion-blur driver, whose per-sample cameras cannot be prepared on the host)
+RTX_DEV void quatFromEuler(V3 e, float& qw, V3& qv)
+{
+    const V3 h = e * 0.5f;
+    const V3 c = mk(cosf(h.x), cosf(h.y), cosf(h.z));
+    const V3 s = mk(sinf(h.x), sinf(h.y), sinf(h.z));
+    qw = c.x * c.y * c.z + s.x * s.y * s.z;
+    qv = mk(s.x * c.y * c.z - c.x * s.y * s.z, c.x * s.y * c.z + s.x * c.y * s.z, c.x * c.y * s.z - s.x * s.y * c.z);
+}
+// Trackball::generateRay, framework/src/trackball.cpp:101-110
+RTX_DEV void cameraRay(const rtx_camera& cam, float px, float py, V3& o, V3& d)
+{
+    const V3 dirCam = normalize(mk(-px * cam.half_width, py * cam.half_height, 1.0f));
+    o = mk(cam.position);
+    d = rotate(cam.quat[0], mk(cam.quat[1], cam.quat[2], cam.quat[3]), dirCam);
+}
+
+} // namespace rtxd

@@ -1,0 +1,1209 @@
+// librtx_hip.so: gfx950 kernels and the C ABI of include/rtx.h.
+//
+// Two persistent kernels do all the work:
+//   traceKernel   batch form of BvhInterface::intersect: 64 rays per wave fetch
+//   renderKernel  the frame drivers: every lane owns one camera sample and runs
+//                 it through a small state machine (radiance ray -> shadow rays
+//                 of the light loop -> reflection children -> ...), so all lanes
+//                 of a wave share one traversal loop whatever their state
+// Waves fetch work units from a global counter until it runs dry.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "rtx.h"
+#include "rtx_device.hpp"
+
+using namespace rtxd;
+
+namespace {
+
+constexpr int kMaxDepth = 8;    // frames of the reflection recursion kept per lane
+constexpr int kMaxLayers = 16;  // transparent layers along one camera ray
+
+// ------------------------------------------------------------ statistics ----
+enum { S_PRIMARY = 0, S_SHADOW, S_BOUNCE, S_BOX, S_TRI, S_SHADED, S_COUNT };
+
+struct LaneCounters {
+    uint32_t primary = 0, shadow = 0, bounce = 0, shaded = 0;
+    TraceCounters tc { 0, 0 };
+};
+
+RTX_DEV uint64_t waveSum(uint32_t v)
+{
+    uint64_t s = v;
+    for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+    return s;
+}
+
+template <bool COUNT>
+RTX_DEV void flushCounters(const LaneCounters& c, unsigned long long* stats)
+{
+    const uint64_t p = waveSum(c.primary), s = waveSum(c.shadow), b = waveSum(c.bounce), sh = waveSum(c.shaded);
+    uint64_t bx = 0, tr = 0;
+    if (COUNT) {
+        bx = waveSum(c.tc.boxTests);
+        tr = waveSum(c.tc.triTests);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[S_PRIMARY], (unsigned long long)p);
+        atomicAdd(&stats[S_SHADOW], (unsigned long long)s);
+        atomicAdd(&stats[S_BOUNCE], (unsigned long long)b);
+        atomicAdd(&stats[S_SHADED], (unsigned long long)sh);
+        if (COUNT) {
+            atomicAdd(&stats[S_BOX], (unsigned long long)bx);
+            atomicAdd(&stats[S_TRI], (unsigned long long)tr);
+        }
+    }
+}
+
+// one work unit per call, wave-uniform
+RTX_DEV uint32_t fetchUnit(uint32_t* counter)
+{
+    uint32_t u = 0;
+    if ((threadIdx.x & 63) == 0)
+        u = atomicAdd(counter, 1u);
+    return __shfl(u, 0, 64);
+}
+
+// ---------------------------------------------------------- trace kernel ----
+struct TraceArgs {
+    DScene sc;
+    rtx_features f;
+    const rtx_ray* rays;
+    rtx_hit* hits;
+    uint64_t n;
+    uint32_t nUnits;
+    uint32_t* workCounter;
+    unsigned long long* stats;
+};
+
+template <int STACK, bool COUNT>
+__global__ void __launch_bounds__(kBlock) traceKernel(TraceArgs A)
+{
+    __shared__ int32_t sRefs[STACK * kBlock];
+    __shared__ float sKeys[STACK * kBlock];
+    LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
+    LaneCounters lc;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        const uint32_t unit = fetchUnit(A.workCounter);
+        if (unit >= A.nUnits)
+            break;
+        const uint64_t i = uint64_t(unit) * 64 + lane;
+        if (i < A.n) {
+            const rtx_ray r = A.rays[i];
+            float t = r.t;
+            Hit h;
+            lc.primary++;
+            const bool any = intersectScene<STACK, COUNT>(A.sc, st, A.f, mk(r.origin), mk(r.direction), t, h, lc.tc);
+            rtx_hit o;
+            o.t = t;
+            o.tri = h.id;
+            o.normal[0] = h.normal.x, o.normal[1] = h.normal.y, o.normal[2] = h.normal.z;
+            o.bary[0] = h.bary.x, o.bary[1] = h.bary.y, o.bary[2] = h.bary.z;
+            o.uv[0] = h.u, o.uv[1] = h.v;
+            o.material = any ? h.material : -1;
+            o.hit = any ? 1 : 0;
+            A.hits[i] = o;
+        }
+    }
+    flushCounters<COUNT>(lc, A.stats);
+}
+
+// --------------------------------------------------------- render kernel ----
+struct RenderArgs {
+    DScene sc;
+    rtx_features f;
+    rtx_camera cam, prev;
+    int32_t W, H, driver, depth, samples, shadowSamples, glossyRays;
+    uint32_t seed;
+    float aperture, focal;
+    // interleaved-tile partition
+    int32_t tileSize, tileRank, tileWorld, tilesX, tilesY, tilesMine;
+    int32_t compact; // 1: write this rank's tiles back to back, 0: Screen layout
+    float* out;
+    // work decomposition: a unit = pixelsPerUnit consecutive pixels of the tile
+    // sequence x lanesPerPixel samples, repeated `rounds` times when a pixel has
+    // more than 64 samples
+    int32_t pixelsPerUnit, lanesPerPixel, rounds;
+    uint32_t nUnits;
+    uint32_t* workCounter;
+    unsigned long long* stats;
+};
+
+// q-th pixel of this rank's tile sequence: tiles in rank order, 8x8 blocks
+// row-major inside a tile, Morton order inside a block.  Returns false for
+// padding outside the image.  yTop counts rows from the top (Screen rows).
+RTX_DEV bool pixelOfSequence(const RenderArgs& A, uint64_t q, int& x, int& yTop, uint64_t& outIndex)
+{
+    const uint32_t ts = A.tileSize, tilePixels = ts * ts;
+    const uint32_t k = uint32_t(q / tilePixels), r = uint32_t(q % tilePixels);
+    if (k >= uint32_t(A.tilesMine))
+        return false;
+    const uint32_t tile = A.tileRank + k * A.tileWorld;
+    const uint32_t tx = tile % A.tilesX, ty = tile / A.tilesX;
+    const uint32_t blocksPerRow = ts / 8;
+    const uint32_t blk = r / 64, m = r % 64;
+    const uint32_t bx = blk % blocksPerRow, by = blk / blocksPerRow;
+    // de-interleave the 6 Morton bits
+    const uint32_t mx = (m & 1) | ((m >> 1) & 2) | ((m >> 2) & 4);
+    const uint32_t my = ((m >> 1) & 1) | ((m >> 2) & 2) | ((m >> 3) & 4);
+    const uint32_t lx = bx * 8 + mx, ly = by * 8 + my;
+    x = int(tx * ts + lx);
+    yTop = int(ty * ts + ly);
+    if (x >= A.W || yTop >= A.H)
+        return false;
+    outIndex = A.compact ? (uint64_t(k) * tilePixels + uint64_t(ly) * ts + lx) : (uint64_t(yTop) * A.W + x);
+    return true;
+}
+
+struct Frame { // one suspended getFinalColor call (src/render.cpp:16-66)
+    V3 Lo, ks, acc;
+    V3 reflO, reflD, nrm;
+    float blur;
+    int32_t count, child, nChildren;
+    uint32_t rngBase;
+};
+
+enum PathState { PS_DONE = 0, PS_RADIANCE = 1, PS_SHADOW = 2 };
+enum Phase { PH_NEXT_LIGHT, PH_AFTER_LIGHTS, PH_NEXT_CHILD, PH_RETURN };
+
+// One camera sample from its first ray to its colour.  Every lane of the wave
+// calls this together; lanes without a sample pass active = false.
+template <int STACK, bool COUNT, bool FULL>
+RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD, bool active, uint32_t rngKey, LaneCounters& lc)
+{
+    const DScene& sc = A.sc;
+    const rtx_features& f = A.f;
+    const bool transparencyDriver = FULL && A.driver == RTX_DRIVER_TRANSPARENCY;
+
+    int state = active ? PS_RADIANCE : PS_DONE;
+    V3 ro = camO, rd = camD; // ray in flight
+    V3 result = mk(0, 0, 0);
+    uint32_t counter = 0;
+    int level = 0, depthLeft = A.depth;
+
+    // shading point of the current getFinalColor call
+    V3 Ro = ro, Rd = rd, hp = mk(0, 0, 0), visN = mk(0, 0, 0), albedo = mk(0, 0, 0), ks = mk(0, 0, 0), hitN = mk(0, 0, 0);
+    float shin = 1.f, Rt = 0.f;
+    V3 Lo = mk(0, 0, 0), avg = mk(0, 0, 0), sh = mk(0, 0, 0), samplePos = mk(0, 0, 0);
+    int li = 0, si = 0;
+
+    Frame frames[FULL ? kMaxDepth : 1];
+    // transparency chain (src/transparency.cpp:6-20): alpha and colour of each
+    // layer in front of the last one
+    float layerAlpha[FULL ? kMaxLayers : 1];
+    V3 layerColor[FULL ? kMaxLayers : 1];
+    int nLayers = 0;
+    bool lastLayer = true;
+    V3 nextLayerO = mk(0, 0, 0);
+
+    while (__any(state != PS_DONE)) {
+        float t = kFltMax;
+        Hit hit;
+        bool any = false;
+        if (state != PS_DONE) {
+            if (state == PS_SHADOW)
+                lc.shadow++;
+            else if (level == 0)
+                lc.primary++;
+            else
+                lc.bounce++;
+            any = intersectScene<STACK, COUNT>(sc, st, f, ro, rd, t, hit, lc.tc);
+        }
+        if (state == PS_DONE)
+            continue;
+
+        int phase;
+        V3 value = mk(0, 0, 0);
+        if (state == PS_SHADOW) {
+            // testVisibilityLightSample, src/light.cpp:70-102: the shadow ray runs
+            // from the light sample to the shading point (un-normalised direction)
+            // and must end within 1e-3 of it; a ray that hits nothing counts as blocked
+            const V3 second = ro + t * rd;
+            float vis = 1.0f;
+            if (dot(normalize(samplePos - hp), normalize(visN)) < -1e-6f)
+                vis = 0.0f;
+            else if (double(distance(hp, second)) > 1e-3)
+                vis = 0.0f;
+            const rtx_light& L = sc.lights[li];
+            if (L.type == RTX_LIGHT_POINT) {
+                Lo = Lo + sh * vis;
+                li++;
+            } else {
+                avg = avg + sh * vis;
+                si++;
+                if (si == A.shadowSamples) {
+                    Lo = Lo + avg * float(1.0 / double(float(A.shadowSamples)));
+                    si = 0;
+                    li++;
+                }
+            }
+            phase = PH_NEXT_LIGHT;
+        } else {
+            // result of a radiance ray = body of getFinalColor
+            if (transparencyDriver && level == 0) {
+                const float alpha = (any && hit.material >= 0) ? sc.mats[hit.material].transparency : 1.0f;
+                lastLayer = !any || alpha == 1.0f || nLayers >= kMaxLayers;
+                if (!lastLayer) {
+                    layerAlpha[nLayers] = alpha;
+                    const float adv = float(double(t) + 1e-6);
+                    nextLayerO = ro + mk(adv, adv, adv) * rd;
+                }
+            }
+            if (!any) {
+                value = (f.enable_environment_mapping && FULL) ? envColor(sc, f, rd) : mk(0, 0, 0);
+                phase = PH_RETURN;
+            } else {
+                Ro = ro, Rd = rd, Rt = t;
+                hp = Ro + Rt * Rd;
+                hitN = hit.normal;
+                const rtx_material& m = sc.mats[hit.material];
+                ks = mk(m.ks);
+                shin = m.shininess;
+                if (!f.enable_shading) {
+                    Lo = mk(m.kd);
+                    phase = PH_AFTER_LIGHTS;
+                } else {
+                    lc.shaded++;
+                    albedo = FULL ? albedoOf(sc, f, m, Ro, Rd, hit) : mk(m.kd);
+                    visN = (dot(normalize(hitN), normalize(Ro - hp)) < -1e-6f) ? -hitN : hitN;
+                    Lo = mk(0, 0, 0);
+                    li = 0;
+                    si = 0;
+                    phase = PH_NEXT_LIGHT;
+                }
+            }
+        }
+
+        // advance until the next ray is in flight or the sample is finished
+        bool launched = false;
+        while (!launched) {
+            if (phase == PH_NEXT_LIGHT) {
+                // computeLightContribution, src/light.cpp:139-189
+                phase = PH_AFTER_LIGHTS;
+                while (li < sc.nLights) {
+                    const rtx_light& L = sc.lights[li];
+                    V3 pos, col;
+                    bool sample = false;
+                    if (L.type == RTX_LIGHT_POINT) {
+                        pos = mk(L.p[0]);
+                        col = mk(L.c[0]);
+                        if (!f.enable_hard_shadow) {
+                            Lo = Lo + phong(pos, col, hp, Rd, hitN, albedo, ks, shin);
+                            li++;
+                            continue;
+                        }
+                        sample = true;
+                    } else if (FULL && f.enable_soft_shadow) {
+                        if (si == 0)
+                            avg = mk(0, 0, 0);
+                        if (L.type == RTX_LIGHT_SEGMENT) {
+                            // src/light.cpp:26-32
+                            const V3 e0 = mk(L.p[0]), e1 = mk(L.p[1]);
+                            const float a = keyedUniform(rngKey, counter++);
+                            pos = a * (e1 - e0) + e0;
+                            col = (1 - a) * mk(L.c[0]) + a * mk(L.c[1]);
+                        } else {
+                            // src/light.cpp:36-45
+                            const float a1 = keyedUniform(rngKey, counter++);
+                            const V3 c1 = (1 - a1) * mk(L.c[0]) + a1 * mk(L.c[1]);
+                            const V3 c2 = (1 - a1) * mk(L.c[2]) + a1 * mk(L.c[3]);
+                            const float a2 = keyedUniform(rngKey, counter++);
+                            col = (1 - a2) * c1 + a2 * c2;
+                            pos = mk(L.p[0]) + mk(L.p[1]) * a1 + mk(L.p[2]) * a2;
+                        }
+                        sample = true;
+                    }
+                    if (!sample) {
+                        li++;
+                        continue;
+                    }
+                    sh = phong(pos, col, hp, Rd, hitN, albedo, ks, shin);
+                    samplePos = pos;
+                    ro = pos;
+                    rd = hp - pos;
+                    state = PS_SHADOW;
+                    launched = true;
+                    break;
+                }
+                if (launched)
+                    break;
+            }
+            if (phase == PH_AFTER_LIGHTS) {
+                // src/render.cpp:22-52
+                const bool bounce = FULL && f.enable_recursive && depthLeft > 0 && !(ks.x == 0.f && ks.y == 0.f && ks.z == 0.f) && level < kMaxDepth;
+                if (!bounce) {
+                    value = Lo;
+                    phase = PH_RETURN;
+                } else {
+                    Frame& F = frames[level];
+                    F.Lo = Lo;
+                    F.ks = ks;
+                    F.acc = mk(0, 0, 0);
+                    F.count = 0;
+                    F.child = 0;
+                    const V3 r = reflectDir(Rd, hitN);
+                    F.reflO = (Ro + Rd * Rt) + float(1e-5) * r;
+                    F.reflD = r;
+                    F.nrm = normalize(hitN);
+                    if (f.enable_glossy_reflection) {
+                        // the whole fan is drawn before any of it is traced
+                        // (src/shading.cpp:98-105): reserve its draws now
+                        F.nChildren = A.glossyRays;
+                        F.blur = 1.0f / shin;
+                        F.rngBase = counter;
+                        counter += 2u * uint32_t(A.glossyRays);
+                    } else {
+                        F.nChildren = 1;
+                        F.blur = 0.f;
+                        F.rngBase = 0;
+                    }
+                    level++;
+                    depthLeft--;
+                    phase = PH_NEXT_CHILD;
+                }
+            }
+            if (phase == PH_NEXT_CHILD) {
+                Frame& F = frames[level - 1];
+                phase = PH_RETURN;
+                bool exhausted = true;
+                while (F.child < F.nChildren) {
+                    const int k = F.child++;
+                    V3 dir = F.reflD;
+                    if (f.enable_glossy_reflection) {
+                        // returnGlossyRay, src/shading.cpp:67-88
+                        const V3 w = normalize(F.reflD);
+                        const V3 tt = normalize(w - mk(0.1f, 0.0f, 0.0f));
+                        const V3 u = normalize(cross(tt, w));
+                        const V3 v = normalize(cross(w, u));
+                        const float ua = -F.blur / 2.0f + F.blur * keyedUniform(rngKey, F.rngBase + 2u * uint32_t(k));
+                        const float va = -F.blur / 2.0f + F.blur * keyedUniform(rngKey, F.rngBase + 2u * uint32_t(k) + 1u);
+                        dir = F.reflD + (ua * u + va * v);
+                    }
+                    const float cosinus = dot(normalize(dir), F.nrm);
+                    const float sinus = __builtin_sqrtf(1.0f - cosinus * cosinus);
+                    if (cosinus > 0.0f && sinus > 0.0f) {
+                        ro = F.reflO;
+                        rd = dir;
+                        state = PS_RADIANCE;
+                        launched = true;
+                        exhausted = false;
+                        break;
+                    }
+                }
+                if (launched)
+                    break;
+                if (exhausted) {
+                    // color *= 1/count (0 * inf = NaN when no child was traced), Lo + color * ks
+                    const V3 color = F.acc * (1.0f / float(F.count));
+                    value = F.Lo + color * F.ks;
+                    level--;
+                    depthLeft++;
+                }
+            }
+            if (phase == PH_RETURN) {
+                if (level > 0) {
+                    Frame& F = frames[level - 1];
+                    F.acc = F.acc + value;
+                    F.count++;
+                    phase = PH_NEXT_CHILD;
+                    continue;
+                }
+                if (transparencyDriver && !lastLayer) {
+                    layerColor[nLayers++] = value;
+                    ro = nextLayerO;
+                    rd = camD;
+                    state = PS_RADIANCE;
+                    launched = true;
+                    break;
+                }
+                if (transparencyDriver) {
+                    // transparency * front + (1 - transparency) * behind, innermost first
+                    for (int i = nLayers - 1; i >= 0; i--)
+                        value = layerAlpha[i] * layerColor[i] + (1.0f - layerAlpha[i]) * value;
+                }
+                result = value;
+                state = PS_DONE;
+                launched = true;
+            }
+        }
+    }
+    return result;
+}
+
+template <int STACK, bool COUNT, bool FULL>
+__global__ void __launch_bounds__(kBlock) renderKernel(RenderArgs A)
+{
+    __shared__ int32_t sRefs[STACK * kBlock];
+    __shared__ float sKeys[STACK * kBlock];
+    __shared__ float sRed[kBlock * 3];
+    LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
+    LaneCounters lc;
+    const int lane = threadIdx.x & 63;
+    volatile float* red = sRed + (threadIdx.x & ~63) * 3;
+
+    const int slot = lane / A.lanesPerPixel, sub = lane % A.lanesPerPixel;
+    const bool laneUsed = slot < A.pixelsPerUnit;
+    const bool averaging = A.driver == RTX_DRIVER_MRAYS || A.driver == RTX_DRIVER_DOF || A.driver == RTX_DRIVER_MOTION_BLUR;
+
+    for (;;) {
+        const uint32_t unit = fetchUnit(A.workCounter);
+        if (unit >= A.nUnits)
+            break;
+        int x = 0, yTop = 0;
+        uint64_t outIndex = 0;
+        const bool pixelOk = laneUsed && pixelOfSequence(A, uint64_t(unit) * A.pixelsPerUnit + slot, x, yTop, outIndex);
+        const int y = A.H - 1 - yTop; // the reference's y runs bottom-up (src/screen.cpp:37-43)
+        const uint32_t pixelIndex = uint32_t(y) * uint32_t(A.W) + uint32_t(x);
+        // pixel corner, not centre (src/render.cpp:76-79)
+        const float ndcX = float(x) / float(A.W) * 2.0f - 1.0f, ndcY = float(y) / float(A.H) * 2.0f - 1.0f;
+        V3 accum = mk(0, 0, 0);
+        for (int round = 0; round < A.rounds; round++) {
+            const int sample = round * A.lanesPerPixel + sub;
+            const bool active = pixelOk && sample < A.samples;
+            V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+            if (active) {
+                switch (A.driver) {
+                case RTX_DRIVER_MRAYS: {
+                    // src/render.cpp:170-176: x jitter then y jitter, draws 2*(pixel*spp+i)+{1,2}
+                    uint64_t rng = minstdAt((uint64_t(pixelIndex) * uint64_t(A.samples) + uint64_t(sample)) * 2ull);
+                    const float jx = minstdUniform(rng, 0.f, 1.f);
+                    const float jy = minstdUniform(rng, 0.f, 1.f);
+                    cameraRay(A.cam, float(float(x) + jx) / float(A.W) * 2.0f - 1.0f, float(float(y) + jy) / float(A.H) * 2.0f - 1.0f, o, d);
+                } break;
+                case RTX_DRIVER_DOF: {
+                    // src/render.cpp:113-117, src/dof.cpp:9-39
+                    V3 co, cd;
+                    cameraRay(A.cam, ndcX, ndcY, co, cd);
+                    const V3 focalPoint = co + A.focal * cd;
+                    uint64_t rng = minstdAt((uint64_t(pixelIndex) * uint64_t(A.samples) + uint64_t(sample)) * 3ull);
+                    const float sx = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
+                    const float sy = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
+                    const float sz = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
+                    o = co + mk(sx, sy, sz);
+                    d = normalize(focalPoint - o);
+                } break;
+                case RTX_DRIVER_MOTION_BLUR: {
+                    // src/render.cpp:203-247: the samples extrapolate from the current
+                    // pose by the pose change since the previous call
+                    uint64_t rng = minstdAt(uint64_t(pixelIndex) * uint64_t(A.samples) + uint64_t(sample));
+                    const float jitter = minstdUniform(rng, 0.f, 1.f);
+                    const float w = (jitter + float(sample)) / float(A.samples);
+                    const V3 lookAt = mk(A.cam.look_at) + w * (mk(A.cam.look_at) - mk(A.prev.look_at));
+                    const V3 euler = mk(A.cam.euler) + w * (mk(A.cam.euler) - mk(A.prev.euler));
+                    const float dist = A.cam.distance + w * (A.cam.distance - A.prev.distance);
+                    float qw;
+                    V3 qv;
+                    quatFromEuler(euler, qw, qv);
+                    const V3 dirCam = normalize(mk(-ndcX * A.cam.half_width, ndcY * A.cam.half_height, 1.0f));
+                    o = lookAt + rotate(qw, qv, mk(0, 0, -dist));
+                    d = rotate(qw, qv, dirCam);
+                } break;
+                default:
+                    cameraRay(A.cam, ndcX, ndcY, o, d);
+                    break;
+                }
+            }
+            const uint32_t key = sampleKey(A.seed, pixelIndex, uint32_t(sample));
+            const V3 c = tracePath<STACK, COUNT, FULL>(A, st, o, d, active, key, lc);
+            if (!averaging) {
+                accum = c;
+            } else {
+                // the reference adds the samples of a pixel one after another in
+                // sample order; reproduce that order exactly through LDS
+                red[lane * 3 + 0] = c.x;
+                red[lane * 3 + 1] = c.y;
+                red[lane * 3 + 2] = c.z;
+                __builtin_amdgcn_wave_barrier();
+                if (pixelOk && sub == 0) {
+                    const int n = min(A.lanesPerPixel, A.samples - round * A.lanesPerPixel);
+                    for (int j = 0; j < n; j++) {
+                        const volatile float* q = red + (lane + j) * 3;
+                        accum = accum + mk(q[0], q[1], q[2]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (pixelOk && sub == 0) {
+            V3 px = accum;
+            if (A.driver == RTX_DRIVER_MRAYS) {
+                const float inv = 1.0f / (float(A.samples) * 1.0f);
+                px = accum * mk(inv, inv, inv);
+            } else if (A.driver == RTX_DRIVER_DOF) {
+                const float inv = 1.0f / float(A.samples);
+                px = accum * mk(inv, inv, inv);
+            } else if (A.driver == RTX_DRIVER_MOTION_BLUR) {
+                px = accum / float(A.samples);
+            }
+            float* dst = A.out + outIndex * 3;
+            dst[0] = px.x;
+            dst[1] = px.y;
+            dst[2] = px.z;
+        }
+    }
+    flushCounters<COUNT>(lc, A.stats);
+}
+
+// scatter gathered compact tile buffers into a Screen-layout frame
+__global__ void detileKernel(const float* tiles, float* out, int W, int H, int ts, int tilesX, int tilesY, int world, int tilesPerRank)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t n = uint64_t(W) * H;
+    if (i >= n)
+        return;
+    const int x = int(i % W), yTop = int(i / W);
+    const int tx = x / ts, ty = yTop / ts;
+    const int tile = ty * tilesX + tx;
+    const int rank = tile % world, k = tile / world;
+    const uint64_t src = (uint64_t(rank) * tilesPerRank + k) * ts * ts + uint64_t(yTop - ty * ts) * ts + (x - tx * ts);
+    out[i * 3 + 0] = tiles[src * 3 + 0];
+    out[i * 3 + 1] = tiles[src * 3 + 1];
+    out[i * 3 + 2] = tiles[src * 3 + 2];
+}
+
+// ================================================================= host ====
+thread_local char g_err[512] = "";
+void setErr(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+#define HIP_TRY(expr)                                                                 \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            setErr("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RTX_ERR_DEVICE;                                                    \
+        }                                                                             \
+    } while (0)
+
+struct DeviceCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t* workCounter = nullptr;          // device
+    unsigned long long* stats = nullptr;      // device, S_COUNT words
+    int numCUs = 0;
+    std::mutex launch;                        // one frame / batch at a time per GPU
+};
+thread_local DeviceCtx* g_ctx = nullptr;
+std::mutex g_ctxMutex;
+DeviceCtx g_ctxs[64];
+
+} // namespace
+
+struct rtx_scene {
+    int device = -1;
+    int refs = 1;
+    DScene d {};
+    void* buffers[10] = {};
+    int nBuffers = 0;
+    int numLevels = 0;
+    bool hasEnv = false;
+};
+
+namespace {
+
+template <class T>
+int upload(rtx_scene* s, const T* src, size_t count, const T** dst)
+{
+    *dst = nullptr;
+    // an empty array still gets a valid pointer so kernels never see NULL
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->buffers[s->nBuffers++] = p;
+    HIP_TRY(hipMemset(p, 0, bytes));
+    if (count)
+        HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T*>(p);
+    return RTX_OK;
+}
+
+int pickStack(int numLevels)
+{
+    // nearer-child-first depth-first traversal holds at most one entry per level
+    if (numLevels <= 16)
+        return 16;
+    if (numLevels <= 24)
+        return 24;
+    if (numLevels <= 32)
+        return 32;
+    if (numLevels <= 64)
+        return 64;
+    return -1;
+}
+
+int gridFor(const DeviceCtx* c, const void* kernel)
+{
+    int perCU = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, 0) != hipSuccess || perCU < 1)
+        perCU = 2;
+    perCU = std::min(perCU, 8);
+    return c->numCUs * perCU;
+}
+
+template <int STACK>
+int launchTrace(DeviceCtx* c, const TraceArgs& A, bool count)
+{
+    const void* k = count ? (const void*)traceKernel<STACK, true> : (const void*)traceKernel<STACK, false>;
+    const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.nUnits + 3) / 4)));
+    if (count)
+        hipLaunchKernelGGL((traceKernel<STACK, true>), dim3(grid), dim3(kBlock), 0, c->stream, A);
+    else
+        hipLaunchKernelGGL((traceKernel<STACK, false>), dim3(grid), dim3(kBlock), 0, c->stream, A);
+    return RTX_OK;
+}
+
+template <int STACK>
+int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, bool full)
+{
+#define RTX_LAUNCH(CNT, FULLV)                                                                                     \
+    {                                                                                                              \
+        const void* k = (const void*)renderKernel<STACK, CNT, FULLV>;                                              \
+        const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.nUnits + 3) / 4)));                       \
+        hipLaunchKernelGGL((renderKernel<STACK, CNT, FULLV>), dim3(grid), dim3(kBlock), 0, c->stream, A);          \
+    }
+    if (count && full)
+        RTX_LAUNCH(true, true)
+    else if (count)
+        RTX_LAUNCH(true, false)
+    else if (full)
+        RTX_LAUNCH(false, true)
+    else
+        RTX_LAUNCH(false, false)
+#undef RTX_LAUNCH
+    return RTX_OK;
+}
+
+int checkCtx(const rtx_scene* scene)
+{
+    if (!g_ctx) {
+        setErr("rtx_init has not been called on this thread");
+        return RTX_ERR_NOT_INIT;
+    }
+    if (scene && scene->device != g_ctx->device) {
+        setErr("scene lives on device %d, this thread uses device %d", scene->device, g_ctx->device);
+        return RTX_ERR_INVALID;
+    }
+    return RTX_OK;
+}
+
+double nowMs()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// environment switch for the per-ray work counters (box / triangle tests): they
+// cost registers, so they are off unless asked for
+bool wantCounters()
+{
+    const char* e = getenv("RTX_COUNT_TESTS");
+    return e && e[0] == '1';
+}
+
+int fetchStats(DeviceCtx* c, rtx_stats* stats, double t0)
+{
+    float ms = 0.f;
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (stats) {
+        unsigned long long h[S_COUNT];
+        HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
+        stats->rays_primary = h[S_PRIMARY];
+        stats->rays_shadow = h[S_SHADOW];
+        stats->rays_bounce = h[S_BOUNCE];
+        stats->box_tests = h[S_BOX];
+        stats->tri_tests = h[S_TRI];
+        stats->shaded_hits = h[S_SHADED];
+        stats->kernel_ms = ms;
+        stats->total_ms = nowMs() - t0;
+    }
+    return RTX_OK;
+}
+
+int traceImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* dHits, const rtx_features* f, rtx_stats* stats, double t0)
+{
+    DeviceCtx* c = g_ctx;
+    std::lock_guard<std::mutex> launchLock(c->launch);
+    if (n > (size_t(1) << 37)) {
+        setErr("rtx_trace: %zu rays exceed the 2^37 limit", n);
+        return RTX_ERR_LIMIT;
+    }
+    const int stack = pickStack(scene->numLevels);
+    if (stack < 0) {
+        setErr("BVH has %d levels; the device traversal stack holds 64", scene->numLevels);
+        return RTX_ERR_LIMIT;
+    }
+    TraceArgs A;
+    A.sc = scene->d;
+    A.f = *f;
+    A.rays = dRays;
+    A.hits = dHits;
+    A.n = n;
+    A.nUnits = uint32_t((n + 63) / 64);
+    A.workCounter = c->workCounter;
+    A.stats = c->stats;
+    HIP_TRY(hipMemsetAsync(c->workCounter, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * S_COUNT, c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (n) {
+        const bool count = wantCounters();
+        switch (stack) {
+        case 16: launchTrace<16>(c, A, count); break;
+        case 24: launchTrace<24>(c, A, count); break;
+        case 32: launchTrace<32>(c, A, count); break;
+        default: launchTrace<64>(c, A, count); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    return fetchStats(c, stats, t0);
+}
+
+struct TileGeom {
+    int ts, tilesX, tilesY, world, rank, tilesMine, tilesPerRank;
+};
+int tileGeom(const rtx_render_params* p, TileGeom& g)
+{
+    g.ts = p->tile_size > 0 ? p->tile_size : 32;
+    if (g.ts % 8 != 0 || g.ts > 1024) {
+        setErr("tile_size must be a multiple of 8 up to 1024 (got %d)", g.ts);
+        return RTX_ERR_INVALID;
+    }
+    if (p->width <= 0 || p->height <= 0 || p->width > 32768 || p->height > 32768) {
+        setErr("frame size %dx%d out of range", p->width, p->height);
+        return RTX_ERR_INVALID;
+    }
+    g.world = p->tile_world > 1 ? p->tile_world : 1;
+    g.rank = p->tile_world > 1 ? p->tile_rank : 0;
+    if (g.rank < 0 || g.rank >= g.world) {
+        setErr("tile_rank %d outside tile_world %d", g.rank, g.world);
+        return RTX_ERR_INVALID;
+    }
+    g.tilesX = (p->width + g.ts - 1) / g.ts;
+    g.tilesY = (p->height + g.ts - 1) / g.ts;
+    const int total = g.tilesX * g.tilesY;
+    g.tilesPerRank = (total + g.world - 1) / g.world;
+    g.tilesMine = total > g.rank ? (total - g.rank + g.world - 1) / g.world : 0;
+    return RTX_OK;
+}
+
+int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dOut, bool compact, rtx_stats* stats, double t0)
+{
+    DeviceCtx* c = g_ctx;
+    std::lock_guard<std::mutex> launchLock(c->launch);
+    TileGeom g;
+    if (int rc = tileGeom(p, g))
+        return rc;
+    const int driver = p->driver;
+    if (driver < RTX_DRIVER_PLAIN || driver > RTX_DRIVER_MOTION_BLUR) {
+        setErr("unknown driver %d", driver);
+        return RTX_ERR_INVALID;
+    }
+    const int stack = pickStack(scene->numLevels);
+    if (stack < 0) {
+        setErr("BVH has %d levels; the device traversal stack holds 64", scene->numLevels);
+        return RTX_ERR_LIMIT;
+    }
+    RenderArgs A;
+    A.sc = scene->d;
+    A.f = *f;
+    A.cam = *cam;
+    A.prev = p->prev_camera;
+    A.W = p->width;
+    A.H = p->height;
+    A.driver = driver;
+    const bool sampled = driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF || driver == RTX_DRIVER_MOTION_BLUR;
+    A.depth = p->ray_depth >= 0 ? p->ray_depth : ((driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF) ? 0 : 1);
+    if (A.depth > kMaxDepth) {
+        setErr("ray_depth %d exceeds the limit of %d", A.depth, kMaxDepth);
+        return RTX_ERR_LIMIT;
+    }
+    A.samples = !sampled ? 1 : (p->samples > 0 ? p->samples : (driver == RTX_DRIVER_MRAYS ? 64 : driver == RTX_DRIVER_DOF ? 100 : 7));
+    A.shadowSamples = p->shadow_samples > 0 ? p->shadow_samples : 50;
+    A.glossyRays = p->glossy_rays > 0 ? p->glossy_rays : 5;
+    A.seed = p->seed;
+    A.aperture = p->aperture > 0.f ? p->aperture : 0.1f;
+    A.focal = p->focal_length > 0.f ? p->focal_length : 2.0f;
+    A.tileSize = g.ts;
+    A.tileRank = g.rank;
+    A.tileWorld = g.world;
+    A.tilesX = g.tilesX;
+    A.tilesY = g.tilesY;
+    A.tilesMine = g.tilesMine;
+    A.compact = compact ? 1 : 0;
+    A.out = dOut;
+    A.lanesPerPixel = std::min(A.samples, 64);
+    A.pixelsPerUnit = 64 / A.lanesPerPixel;
+    A.rounds = (A.samples + 63) / 64;
+    const uint64_t seqPixels = uint64_t(g.tilesMine) * g.ts * g.ts;
+    const uint64_t units = (seqPixels + A.pixelsPerUnit - 1) / A.pixelsPerUnit;
+    if (units > 0xffffffffull) {
+        setErr("frame too large for one launch");
+        return RTX_ERR_LIMIT;
+    }
+    A.nUnits = uint32_t(units);
+    A.workCounter = c->workCounter;
+    A.stats = c->stats;
+
+    // the full kernel carries the reflection / transparency / area-light /
+    // texture / environment machinery; the lean one is enough otherwise
+    const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || driver == RTX_DRIVER_TRANSPARENCY;
+
+    HIP_TRY(hipMemsetAsync(c->workCounter, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * S_COUNT, c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (A.nUnits) {
+        const bool count = wantCounters();
+        switch (stack) {
+        case 16: launchRender<16>(c, A, count, full); break;
+        case 24: launchRender<24>(c, A, count, full); break;
+        case 32: launchRender<32>(c, A, count, full); break;
+        default: launchRender<64>(c, A, count, full); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    return fetchStats(c, stats, t0);
+}
+
+} // namespace
+
+// =================================================================== ABI ====
+extern "C" {
+
+const char* rtx_last_error(void) { return g_err; }
+
+int rtx_init(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        setErr("no HIP device available");
+        return RTX_ERR_DEVICE;
+    }
+    if (device < 0 || device >= count || device >= 64) {
+        setErr("device %d out of range (0..%d)", device, count - 1);
+        return RTX_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> lock(g_ctxMutex);
+    DeviceCtx* c = &g_ctxs[device];
+    if (c->device < 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        c->numCUs = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&c->ev0));
+        HIP_TRY(hipEventCreate(&c->ev1));
+        HIP_TRY(hipMalloc((void**)&c->workCounter, 256));
+        HIP_TRY(hipMalloc((void**)&c->stats, 256));
+        c->device = device;
+    }
+    g_ctx = c;
+    g_err[0] = 0;
+    return RTX_OK;
+}
+
+rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
+{
+    if (checkCtx(nullptr))
+        return nullptr;
+    if (!d) {
+        setErr("rtx_scene_create: NULL description");
+        return nullptr;
+    }
+    // shape checks: everything the kernels index must be in range
+    if (d->n_tris && (!d->tris || !d->tri_attrs)) {
+        setErr("rtx_scene_create: %u triangles but NULL arrays", d->n_tris);
+        return nullptr;
+    }
+    if (d->n_tris > (1u << 30) || d->n_nodes > (1u << 30)) {
+        setErr("rtx_scene_create: scene too large");
+        return nullptr;
+    }
+    const bool emptyTree = d->root_ref == INT32_MIN;
+    if (!emptyTree) {
+        auto refOk = [&](int32_t r) { return r >= 0 ? uint32_t(r) < d->n_nodes : uint32_t(~r) < d->n_tris; };
+        if (!refOk(d->root_ref)) {
+            setErr("rtx_scene_create: root reference %d out of range", d->root_ref);
+            return nullptr;
+        }
+        for (uint32_t i = 0; i < d->n_nodes; i++)
+            if (!refOk(d->nodes[i].ref0) || !refOk(d->nodes[i].ref1)) {
+                setErr("rtx_scene_create: node %u has a child reference out of range", i);
+                return nullptr;
+            }
+        // every leaf must be terminated inside the array
+        if (d->n_tris && !(d->tris[d->n_tris - 1].flags & RTX_TRI_LAST_IN_LEAF)) {
+            setErr("rtx_scene_create: last triangle record lacks the end-of-leaf flag");
+            return nullptr;
+        }
+    }
+    for (uint32_t i = 0; i < d->n_tris; i++) {
+        if (d->tris[i].material < 0 || uint32_t(d->tris[i].material) >= d->n_materials) {
+            setErr("rtx_scene_create: triangle %u has material %d of %u", i, d->tris[i].material, d->n_materials);
+            return nullptr;
+        }
+        if (d->tris[i].id < 0 || uint32_t(d->tris[i].id) >= d->n_tris) {
+            setErr("rtx_scene_create: triangle %u has id %d of %u", i, d->tris[i].id, d->n_tris);
+            return nullptr;
+        }
+    }
+    for (uint32_t i = 0; i < d->n_spheres; i++)
+        if (d->spheres[i].material < 0 || uint32_t(d->spheres[i].material) >= d->n_materials) {
+            setErr("rtx_scene_create: sphere %u has material %d of %u", i, d->spheres[i].material, d->n_materials);
+            return nullptr;
+        }
+    for (uint32_t i = 0; i < d->n_materials; i++)
+        if (d->materials[i].texture >= int32_t(d->n_textures)) {
+            setErr("rtx_scene_create: material %u has texture %d of %u", i, d->materials[i].texture, d->n_textures);
+            return nullptr;
+        }
+    if (d->envmap.texture >= int32_t(d->n_textures)) {
+        setErr("rtx_scene_create: environment map texture %d of %u", d->envmap.texture, d->n_textures);
+        return nullptr;
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rtx_texture& t = d->textures[i];
+        if (t.levels < 1 || t.levels > RTX_MAX_MIP_LEVELS) {
+            setErr("rtx_scene_create: texture %u has %d levels", i, t.levels);
+            return nullptr;
+        }
+        for (int l = 0; l < t.levels; l++)
+            if (uint64_t(t.offset[l]) + t.count[l] > d->n_texels || t.width[l] < 0 || t.height[l] < 0) {
+                setErr("rtx_scene_create: texture %u level %d outside the texel pool", i, l);
+                return nullptr;
+            }
+    }
+    for (uint32_t i = 0; i < d->n_lights; i++)
+        if (d->lights[i].type < RTX_LIGHT_POINT || d->lights[i].type > RTX_LIGHT_PARALLELOGRAM) {
+            setErr("rtx_scene_create: light %u has unknown type %d", i, d->lights[i].type);
+            return nullptr;
+        }
+
+    rtx_scene* s = new (std::nothrow) rtx_scene;
+    if (!s) {
+        setErr("out of host memory");
+        return nullptr;
+    }
+    s->device = g_ctx->device;
+    s->numLevels = d->num_levels;
+    std::vector<int32_t> idOrder(d->n_tris);
+    for (uint32_t k = 0; k < d->n_tris; k++)
+        idOrder[size_t(d->tris[k].id)] = int32_t(k);
+    const rtx_node* nodes;
+    const rtx_tri* tris;
+    const rtx_tri_attr* attrs;
+    int rc = upload(s, d->nodes, d->n_nodes, &nodes);
+    rc = rc ? rc : upload(s, d->tris, d->n_tris, &tris);
+    rc = rc ? rc : upload(s, d->tri_attrs, d->n_tris, &attrs);
+    rc = rc ? rc : upload(s, idOrder.data(), idOrder.size(), &s->d.idOrder);
+    rc = rc ? rc : upload(s, d->materials, d->n_materials, &s->d.mats);
+    rc = rc ? rc : upload(s, d->textures, d->n_textures, &s->d.textures);
+    rc = rc ? rc : upload(s, d->texels, size_t(d->n_texels) * 3, &s->d.texels);
+    rc = rc ? rc : upload(s, d->lights, d->n_lights, &s->d.lights);
+    rc = rc ? rc : upload(s, d->spheres, d->n_spheres, &s->d.spheres);
+    if (rc) {
+        rtx_scene_destroy(s);
+        return nullptr;
+    }
+    s->d.nodes = reinterpret_cast<const float4*>(nodes);
+    s->d.tris = reinterpret_cast<const float4*>(tris);
+    s->d.attrs = reinterpret_cast<const float4*>(attrs);
+    s->d.env = d->envmap;
+    s->d.nTris = int32_t(d->n_tris);
+    s->d.nLights = int32_t(d->n_lights);
+    s->d.nSpheres = int32_t(d->n_spheres);
+    s->d.nMaterials = int32_t(d->n_materials);
+    s->d.rootRef = d->root_ref;
+    memcpy(s->d.rootLo, d->root_lo, sizeof(s->d.rootLo));
+    memcpy(s->d.rootHi, d->root_hi, sizeof(s->d.rootHi));
+    return s;
+}
+
+void rtx_scene_retain(rtx_scene* s)
+{
+    if (s) {
+        std::lock_guard<std::mutex> lock(g_ctxMutex);
+        s->refs++;
+    }
+}
+
+void rtx_scene_destroy(rtx_scene* s)
+{
+    if (!s)
+        return;
+    {
+        std::lock_guard<std::mutex> lock(g_ctxMutex);
+        if (--s->refs > 0)
+            return;
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(s->device);
+    for (int i = 0; i < s->nBuffers; i++)
+        (void)hipFree(s->buffers[i]);
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
+    delete s;
+}
+
+int rtx_trace_device(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* dHits, const rtx_features* f, rtx_stats* stats)
+{
+    const double t0 = nowMs();
+    if (int rc = checkCtx(scene))
+        return rc;
+    if (!scene || !f || (n && (!dRays || !dHits))) {
+        setErr("rtx_trace_device: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    return traceImpl(scene, dRays, n, dHits, f, stats, t0);
+}
+
+int rtx_trace(const rtx_scene* scene, const rtx_ray* rays, size_t n, rtx_hit* hits, const rtx_features* f, rtx_stats* stats)
+{
+    const double t0 = nowMs();
+    if (int rc = checkCtx(scene))
+        return rc;
+    if (!scene || !f || (n && (!rays || !hits))) {
+        setErr("rtx_trace: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    if (n == 0)
+        return traceImpl(scene, nullptr, 0, nullptr, f, stats, t0);
+    rtx_ray* dRays = nullptr;
+    rtx_hit* dHits = nullptr;
+    HIP_TRY(hipMalloc((void**)&dRays, n * sizeof(rtx_ray)));
+    if (hipMalloc((void**)&dHits, n * sizeof(rtx_hit)) != hipSuccess) {
+        (void)hipFree(dRays);
+        setErr("rtx_trace: out of device memory for %zu hits", n);
+        return RTX_ERR_DEVICE;
+    }
+    int rc = RTX_OK;
+    if (hipMemcpyAsync(dRays, rays, n * sizeof(rtx_ray), hipMemcpyHostToDevice, g_ctx->stream) != hipSuccess) {
+        setErr("rtx_trace: ray upload failed");
+        rc = RTX_ERR_DEVICE;
+    }
+    rc = rc ? rc : traceImpl(scene, dRays, n, dHits, f, stats, t0);
+    if (!rc && hipMemcpy(hits, dHits, n * sizeof(rtx_hit), hipMemcpyDeviceToHost) != hipSuccess) {
+        setErr("rtx_trace: hit download failed");
+        rc = RTX_ERR_DEVICE;
+    }
+    (void)hipFree(dRays);
+    (void)hipFree(dHits);
+    if (stats)
+        stats->total_ms = nowMs() - t0;
+    return rc;
+}
+
+int rtx_render_device(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dOut, rtx_stats* stats)
+{
+    const double t0 = nowMs();
+    if (int rc = checkCtx(scene))
+        return rc;
+    if (!scene || !cam || !f || !p || !dOut) {
+        setErr("rtx_render_device: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    return renderImpl(scene, cam, f, p, dOut, false, stats, t0);
+}
+
+int rtx_render_tiles_device(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dTiles, rtx_stats* stats)
+{
+    const double t0 = nowMs();
+    if (int rc = checkCtx(scene))
+        return rc;
+    if (!scene || !cam || !f || !p || !dTiles) {
+        setErr("rtx_render_tiles_device: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    return renderImpl(scene, cam, f, p, dTiles, true, stats, t0);
+}
+
+int rtx_render(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* out, rtx_stats* stats)
+{
+    const double t0 = nowMs();
+    if (int rc = checkCtx(scene))
+        return rc;
+    if (!scene || !cam || !f || !p || !out) {
+        setErr("rtx_render: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    TileGeom g;
+    if (int rc = tileGeom(p, g))
+        return rc;
+    const size_t bytes = size_t(p->width) * size_t(p->height) * 3 * sizeof(float);
+    float* dOut = nullptr;
+    HIP_TRY(hipMalloc((void**)&dOut, bytes));
+    int rc = RTX_OK;
+    // pixels of other ranks' tiles keep the caller's values
+    if (g.world > 1 && (hipMemcpyAsync(dOut, out, bytes, hipMemcpyHostToDevice, g_ctx->stream) != hipSuccess || hipStreamSynchronize(g_ctx->stream) != hipSuccess)) {
+        setErr("rtx_render: framebuffer upload failed");
+        rc = RTX_ERR_DEVICE;
+    }
+    rc = rc ? rc : renderImpl(scene, cam, f, p, dOut, false, stats, t0);
+    if (!rc && hipMemcpy(out, dOut, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        setErr("rtx_render: framebuffer download failed");
+        rc = RTX_ERR_DEVICE;
+    }
+    (void)hipFree(dOut);
+    if (stats)
+        stats->total_ms = nowMs() - t0;
+    return rc;
+}
+
+int rtx_tiles_per_rank(const rtx_render_params* p)
+{
+    TileGeom g;
+    if (!p) {
+        setErr("rtx_tiles_per_rank: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    if (int rc = tileGeom(p, g))
+        return rc;
+    return g.tilesPerRank;
+}
+
+int rtx_detile_device(const float* dAllTiles, const rtx_render_params* p, float* dOut)
+{
+    if (int rc = checkCtx(nullptr))
+        return rc;
+    if (!dAllTiles || !p || !dOut) {
+        setErr("rtx_detile_device: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    TileGeom g;
+    if (int rc = tileGeom(p, g))
+        return rc;
+    const uint64_t n = uint64_t(p->width) * p->height;
+    const int block = 256;
+    hipLaunchKernelGGL(detileKernel, dim3(uint32_t((n + block - 1) / block)), dim3(block), 0, g_ctx->stream, dAllTiles, dOut, p->width, p->height, g.ts,
+        g.tilesX, g.tilesY, g.world, g.tilesPerRank);
+    HIP_TRY(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_synchronize(void)
+{
+    if (int rc = checkCtx(nullptr))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(g_ctx->stream));
+    return RTX_OK;
+}
+
+} // extern "C"

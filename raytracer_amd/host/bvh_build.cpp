@@ -1,0 +1,319 @@
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <stdexcept>
+
+namespace rt {
+namespace {
+
+struct Box {
+    vec3 lo, hi;
+};
+struct Prim {
+    int mesh, tri;
+    vec3 centroid;
+    Box box;
+};
+
+inline float mn3(float a, float b, float c) { return std::min({ a, b, c }); }
+inline float mx3(float a, float b, float c) { return std::max({ a, b, c }); }
+
+// mergeAABs, src/bounding_volume_hierarchy.cpp:56-62
+Box merge(const Box& a, const Box& b)
+{
+    auto mn = [](vec3 p, vec3 q) { return vec3(std::min(p.x, q.x), std::min(p.y, q.y), std::min(p.z, q.z)); };
+    auto mx = [](vec3 p, vec3 q) { return vec3(std::max(p.x, q.x), std::max(p.y, q.y), std::max(p.z, q.z)); };
+    return Box { mn(mn(a.lo, b.lo), mn(a.hi, b.hi)), mx(mx(a.lo, b.lo), mx(a.hi, b.hi)) };
+}
+
+struct Builder {
+    const Scene& scene;
+    const std::vector<Prim>& prims;
+    FlatScene& out;
+    int maxDepth;
+    bool sah;
+
+    struct Sub {
+        int32_t ref, cnt;
+        Box box;
+        int levels, leaves;
+    };
+
+    void emitTriangle(size_t id, bool last)
+    {
+        const Prim& p = prims[id];
+        const Mesh& m = scene.meshes[size_t(p.mesh)];
+        const uvec3 t = m.triangles[size_t(p.tri)];
+        const Vertex &a = m.vertices[t.x], &b = m.vertices[t.y], &c = m.vertices[t.z];
+        rtx_tri r;
+        std::memcpy(r.v0, &a.position, 12);
+        std::memcpy(r.v1, &b.position, 12);
+        std::memcpy(r.v2, &c.position, 12);
+        // plane as src/intersect.cpp:50-58 computes it per test; the reference
+        // rejects a triangle whose cross product has zero length
+        // (src/intersect.cpp:16-19), encoded here as a NaN plane
+        const float nan = std::numeric_limits<float>::quiet_NaN();
+        vec3 n(nan, nan, nan);
+        float d = nan;
+        if (!(length(cross(c.position - a.position, b.position - a.position)) == 0.f)) {
+            n = normalize(cross(b.position - a.position, c.position - a.position));
+            d = dot(a.position, n);
+        }
+        std::memcpy(r.n, &n, 12);
+        r.d = d;
+        r.id = int32_t(id);
+        r.material = p.mesh; // one material per mesh
+        r.flags = last ? RTX_TRI_LAST_IN_LEAF : 0;
+        out.tris.push_back(r);
+        rtx_tri_attr at;
+        std::memcpy(at.n0, &a.normal, 12);
+        std::memcpy(at.n1, &b.normal, 12);
+        std::memcpy(at.n2, &c.normal, 12);
+        std::memcpy(at.uv0, &a.texCoord, 8);
+        std::memcpy(at.uv1, &b.texCoord, 8);
+        std::memcpy(at.uv2, &c.texCoord, 8);
+        at.pad = 0.f;
+        out.attrs.push_back(at);
+    }
+
+    // bvhSplitHelper, src/bounding_volume_hierarchy.cpp:101-138
+    Sub build(size_t* idx, size_t n, int direction, int depth)
+    {
+        if ((maxDepth > -1 && maxDepth <= depth) || n < 2) {
+            Box box = prims[idx[0]].box;
+            for (size_t i = 0; i < n; i++)
+                box = merge(box, prims[idx[i]].box);
+            const int32_t first = int32_t(out.tris.size());
+            for (size_t i = 0; i < n; i++)
+                emitTriangle(idx[i], i + 1 == n);
+            return Sub { ~first, int32_t(n), box, 1, 1 };
+        }
+        auto cmp = [this, direction](const size_t a, const size_t b) {
+            return prims[a].centroid[direction] > prims[b].centroid[direction];
+        };
+        size_t split;
+        if (sah) {
+            // getSAHBestSplit, src/bounding_volume_hierarchy.cpp:76-98
+            std::sort(idx, idx + n, cmp);
+            const float minimum = prims[idx[0]].centroid[direction], maximum = prims[idx[n - 1]].centroid[direction];
+            float minCost = std::numeric_limits<float>::infinity();
+            size_t minIndex = 0;
+            for (size_t i = 1; i < n; i++) {
+                const float cost = -((prims[idx[i - 1]].centroid[direction] - minimum) * i + (maximum - prims[idx[i]].centroid[direction]) * (n - i));
+                if (minCost > cost) {
+                    minCost = cost;
+                    minIndex = i;
+                }
+            }
+            split = minIndex;
+        } else {
+            // getMedian, src/bounding_volume_hierarchy.cpp:65-73
+            std::nth_element(idx, idx + n / 2, idx + n, cmp);
+            split = n / 2;
+        }
+        const int32_t self = int32_t(out.nodes.size());
+        out.nodes.emplace_back();
+        const Sub l = build(idx, split, (direction + 1) % 3, depth + 1);
+        const Sub r = build(idx + split, n - split, (direction + 1) % 3, depth + 1);
+        rtx_node& nd = out.nodes[size_t(self)];
+        std::memcpy(nd.lo0, &l.box.lo, 12);
+        std::memcpy(nd.hi0, &l.box.hi, 12);
+        std::memcpy(nd.lo1, &r.box.lo, 12);
+        std::memcpy(nd.hi1, &r.box.hi, 12);
+        nd.ref0 = l.ref;
+        nd.ref1 = r.ref;
+        nd.cnt0 = l.ref < 0 ? l.cnt : 0;
+        nd.cnt1 = r.ref < 0 ? r.cnt : 0;
+        return Sub { self, 0, merge(l.box, r.box), std::max(l.levels, r.levels) + 1, l.leaves + r.leaves };
+    }
+};
+
+// transformToMipMap, src/main.cpp:745-771.  The reference reads one row / column
+// past a level whose size is odd (undefined there); those reads count as 0.
+int addTexture(FlatScene& out, const Image& img)
+{
+    rtx_texture t;
+    std::memset(&t, 0, sizeof(t));
+    int w = img.width, h = img.height;
+    std::vector<vec3> cur = img.pixels;
+    cur.resize(size_t(w) * size_t(h));
+    int level = 0;
+    for (;;) {
+        t.width[level] = w;
+        t.height[level] = h;
+        t.offset[level] = uint32_t(out.texels.size() / 3);
+        t.count[level] = uint32_t(cur.size());
+        for (const vec3& p : cur) {
+            out.texels.push_back(p.x);
+            out.texels.push_back(p.y);
+            out.texels.push_back(p.z);
+        }
+        level++;
+        if (cur.size() <= 1 || level >= RTX_MAX_MIP_LEVELS)
+            break;
+        std::vector<vec3> next;
+        auto at = [&](size_t i) { return i < cur.size() ? cur[i] : vec3(0, 0, 0); };
+        const size_t W = size_t(w), H = size_t(h);
+        for (size_t i = 0; i < H; i += 2)
+            for (size_t j = 0; j < W; j += 2) {
+                vec3 avg = at(i * W + j) + at(i * W + j + 1) + at((i + 1) * W + j) + at((i + 1) * W + j + 1);
+                next.push_back(avg * (1.0f / 4.0f));
+            }
+        w /= 2;
+        h /= 2;
+        cur.swap(next);
+    }
+    t.levels = level;
+    out.textures.push_back(t);
+    return int(out.textures.size()) - 1;
+}
+
+rtx_material toMaterial(FlatScene& out, const Material& m, std::map<const Image*, int>& texIndex)
+{
+    rtx_material r;
+    std::memset(&r, 0, sizeof(r));
+    std::memcpy(r.kd, &m.kd, 12);
+    std::memcpy(r.ks, &m.ks, 12);
+    r.shininess = m.shininess;
+    r.transparency = m.transparency;
+    r.texture = -1;
+    if (m.kdTexture) {
+        auto it = texIndex.find(m.kdTexture.get());
+        if (it == texIndex.end())
+            it = texIndex.emplace(m.kdTexture.get(), addTexture(out, *m.kdTexture)).first;
+        r.texture = it->second;
+    }
+    return r;
+}
+
+} // namespace
+
+FlatScene flattenScene(const Scene& scene, const Features& features)
+{
+    FlatScene out;
+    std::map<const Image*, int> texIndex;
+    // materials: one per mesh (index = mesh index), then one per sphere
+    for (const Mesh& m : scene.meshes)
+        out.materials.push_back(toMaterial(out, m.material, texIndex));
+    for (const Sphere& s : scene.spheres) {
+        rtx_sphere r;
+        std::memset(&r, 0, sizeof(r));
+        std::memcpy(r.center, &s.center, 12);
+        r.radius = s.radius;
+        r.material = int32_t(out.materials.size());
+        out.materials.push_back(toMaterial(out, s.material, texIndex));
+        out.spheres.push_back(r);
+    }
+    for (const auto& l : scene.lights) {
+        rtx_light r;
+        std::memset(&r, 0, sizeof(r));
+        if (std::holds_alternative<PointLight>(l)) {
+            const auto& q = std::get<PointLight>(l);
+            r.type = RTX_LIGHT_POINT;
+            std::memcpy(r.p[0], &q.position, 12);
+            std::memcpy(r.c[0], &q.color, 12);
+        } else if (std::holds_alternative<SegmentLight>(l)) {
+            const auto& q = std::get<SegmentLight>(l);
+            r.type = RTX_LIGHT_SEGMENT;
+            std::memcpy(r.p[0], &q.endpoint0, 12);
+            std::memcpy(r.p[1], &q.endpoint1, 12);
+            std::memcpy(r.c[0], &q.color0, 12);
+            std::memcpy(r.c[1], &q.color1, 12);
+        } else {
+            const auto& q = std::get<ParallelogramLight>(l);
+            r.type = RTX_LIGHT_PARALLELOGRAM;
+            std::memcpy(r.p[0], &q.v0, 12);
+            std::memcpy(r.p[1], &q.edge01, 12);
+            std::memcpy(r.p[2], &q.edge02, 12);
+            std::memcpy(r.c[0], &q.color0, 12);
+            std::memcpy(r.c[1], &q.color1, 12);
+            std::memcpy(r.c[2], &q.color2, 12);
+            std::memcpy(r.c[3], &q.color3, 12);
+        }
+        out.lights.push_back(r);
+    }
+    if (!scene.environmentMap.empty() && scene.environmentMap[0]) {
+        const EnvironmentMap& e = *scene.environmentMap[0];
+        out.envmap.texture = e.texture ? addTexture(out, *e.texture) : -1;
+        // only level 0 of the environment image is ever sampled
+        out.envmap.mapping = e.mappingType == SPHERICAL ? RTX_ENV_SPHERICAL : RTX_ENV_CYLINDRICAL;
+        out.envmap.vfov_radians = radians(e.verticalFieldOfViewDegrees);
+        std::memcpy(out.envmap.background, &e.backgroundColor, 12);
+    }
+
+    // meshTrianglePairs in mesh-major order, src/bounding_volume_hierarchy.cpp:166-175
+    std::vector<Prim> prims;
+    for (size_t mi = 0; mi < scene.meshes.size(); mi++) {
+        const Mesh& m = scene.meshes[mi];
+        for (size_t j = 0; j < m.triangles.size(); j++) {
+            const uvec3 t = m.triangles[j];
+            if (t.x >= m.vertices.size() || t.y >= m.vertices.size() || t.z >= m.vertices.size())
+                throw std::out_of_range("triangle references a vertex outside its mesh");
+            const vec3 p0 = m.vertices[t.x].position, p1 = m.vertices[t.y].position, p2 = m.vertices[t.z].position;
+            Prim p;
+            p.mesh = int(mi);
+            p.tri = int(j);
+            p.centroid = (1.f / 3.f) * (p0 + p1 + p2);
+            p.box = Box { vec3(mn3(p0.x, p1.x, p2.x), mn3(p0.y, p1.y, p2.y), mn3(p0.z, p1.z, p2.z)),
+                vec3(mx3(p0.x, p1.x, p2.x), mx3(p0.y, p1.y, p2.y), mx3(p0.z, p1.z, p2.z)) };
+            prims.push_back(p);
+            out.idMesh.push_back(int32_t(mi));
+            out.idLocal.push_back(int32_t(j));
+        }
+    }
+    const size_t n = prims.size();
+    if (n == 0)
+        return out; // empty tree (e.g. the Spheres scene): rootRef stays INT32_MIN
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++)
+        idx[i] = i;
+    out.tris.reserve(n);
+    out.attrs.reserve(n);
+    out.nodes.reserve(n);
+    // glm::ceil(0.8 * glm::log2((float) n)), src/bounding_volume_hierarchy.cpp:177
+    const int maxDepth = int(std::ceil(0.8 * double(std::log2(float(n)))));
+    Builder b { scene, prims, out, maxDepth, features.extra.enableBvhSahBinning };
+    const Builder::Sub root = b.build(idx.data(), n, 0, 0);
+    out.rootRef = root.ref;
+    out.rootCnt = root.ref < 0 ? root.cnt : 0;
+    std::memcpy(out.rootLo, &root.box.lo, 12);
+    std::memcpy(out.rootHi, &root.box.hi, 12);
+    out.numLevels = root.levels;
+    out.numLeaves = root.leaves;
+    return out;
+}
+
+rtx_scene_desc FlatScene::desc() const
+{
+    rtx_scene_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.nodes = nodes.data();
+    d.n_nodes = uint32_t(nodes.size());
+    d.root_ref = rootRef;
+    d.root_cnt = rootCnt;
+    std::memcpy(d.root_lo, rootLo, 12);
+    std::memcpy(d.root_hi, rootHi, 12);
+    d.tris = tris.data();
+    d.tri_attrs = attrs.data();
+    d.n_tris = uint32_t(tris.size());
+    d.materials = materials.data();
+    d.n_materials = uint32_t(materials.size());
+    d.textures = textures.data();
+    d.n_textures = uint32_t(textures.size());
+    d.texels = texels.data();
+    d.n_texels = texels.size() / 3;
+    d.lights = lights.data();
+    d.n_lights = uint32_t(lights.size());
+    d.spheres = spheres.data();
+    d.n_spheres = uint32_t(spheres.size());
+    d.envmap = envmap;
+    d.num_levels = numLevels;
+    d.num_leaves = numLeaves;
+    return d;
+}
+
+} // namespace rt

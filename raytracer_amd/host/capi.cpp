@@ -1,0 +1,341 @@
+// Flat C entry points over the C++ host layer so that Python (ctypes) can drive
+// it: scene assembly from arrays, host-only flattening (no GPU needed), and the
+// GPU-backed BvhInterface / render drivers.  Errors are returned as negative
+// codes with text in rtxh_last_error().
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "raytracer.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string t_err;
+
+struct HostScene {
+    Scene scene;
+    std::vector<std::unique_ptr<EnvironmentMap>> envs;
+};
+
+vec3 v3(const float* p) { return vec3(p[0], p[1], p[2]); }
+
+Material toMaterial(const float* m, const float* tex, int tw, int th)
+{
+    Material o;
+    o.kd = v3(m);
+    o.ks = v3(m + 3);
+    o.shininess = m[6];
+    o.transparency = m[7];
+    if (tex) {
+        auto img = std::make_shared<Image>();
+        img->width = tw;
+        img->height = th;
+        img->pixels.resize(size_t(tw) * size_t(th));
+        std::memcpy(static_cast<void*>(img->pixels.data()), tex, size_t(tw) * size_t(th) * 12);
+        o.kdTexture = img;
+    }
+    return o;
+}
+
+Features toFeatures(const rtx_features* f)
+{
+    Features o;
+    o.enableShading = f->enable_shading;
+    o.enableRecursive = f->enable_recursive;
+    o.enableHardShadow = f->enable_hard_shadow;
+    o.enableSoftShadow = f->enable_soft_shadow;
+    o.enableNormalInterp = f->enable_normal_interp;
+    o.enableTextureMapping = f->enable_texture_mapping;
+    o.enableAccelStructure = f->enable_accel_structure;
+    o.extra.enableEnvironmentMapping = f->enable_environment_mapping;
+    o.extra.enableBvhSahBinning = f->enable_bvh_sah_binning;
+    o.extra.enableBilinearTextureFiltering = f->enable_bilinear_texture_filtering;
+    o.extra.enableMipmapTextureFiltering = f->enable_mipmap_texture_filtering;
+    o.extra.enableGlossyReflection = f->enable_glossy_reflection;
+    return o;
+}
+
+Trackball toTrackball(const rtx_camera* c, int W, int H)
+{
+    const float aspect = (W == 0 || H == 0) ? 1.0f : float(W) / float(H);
+    Trackball t(aspect, c->fovy, v3(c->look_at), c->distance, c->euler[0], c->euler[1]);
+    t.setCamera(v3(c->look_at), v3(c->euler), c->distance);
+    return t;
+}
+
+template <class F>
+int guarded(F&& fn)
+{
+    try {
+        fn();
+        return 0;
+    } catch (const std::exception& e) {
+        t_err = e.what();
+        return -1;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rtxh_last_error() { return t_err.c_str(); }
+
+int rtxh_select_device(int device)
+{
+    return guarded([&] { selectDevice(device); });
+}
+
+void* rtxh_scene_create() { return new HostScene; }
+void rtxh_scene_free(void* p) { delete static_cast<HostScene*>(p); }
+
+int rtxh_scene_add_mesh(void* p, const float* verts, int nv, const uint32_t* tris, int nt, const float* mat, const float* tex, int tw, int th)
+{
+    return guarded([&] {
+        auto* s = static_cast<HostScene*>(p);
+        Mesh m;
+        m.vertices.resize(size_t(nv));
+        for (int i = 0; i < nv; i++) {
+            const float* v = verts + size_t(i) * 8;
+            m.vertices[size_t(i)].position = v3(v);
+            m.vertices[size_t(i)].normal = v3(v + 3);
+            m.vertices[size_t(i)].texCoord = vec2 { v[6], v[7] };
+        }
+        m.triangles.resize(size_t(nt));
+        for (int i = 0; i < nt; i++) {
+            m.triangles[size_t(i)] = uvec3 { tris[3 * i], tris[3 * i + 1], tris[3 * i + 2] };
+            for (int k = 0; k < 3; k++)
+                if (tris[3 * i + k] >= uint32_t(nv))
+                    throw RtError("triangle index out of range");
+        }
+        m.material = toMaterial(mat, tex, tw, th);
+        s->scene.meshes.push_back(std::move(m));
+    });
+}
+
+int rtxh_scene_add_light(void* p, const rtx_light* l)
+{
+    return guarded([&] {
+        auto* s = static_cast<HostScene*>(p);
+        if (l->type == RTX_LIGHT_POINT)
+            s->scene.lights.emplace_back(PointLight { v3(l->p[0]), v3(l->c[0]) });
+        else if (l->type == RTX_LIGHT_SEGMENT)
+            s->scene.lights.emplace_back(SegmentLight { v3(l->p[0]), v3(l->p[1]), v3(l->c[0]), v3(l->c[1]) });
+        else if (l->type == RTX_LIGHT_PARALLELOGRAM)
+            s->scene.lights.emplace_back(ParallelogramLight { v3(l->p[0]), v3(l->p[1]), v3(l->p[2]), v3(l->c[0]), v3(l->c[1]), v3(l->c[2]), v3(l->c[3]) });
+        else
+            throw RtError("unknown light type");
+    });
+}
+
+int rtxh_scene_add_sphere(void* p, const float* center, float radius, const float* mat)
+{
+    return guarded([&] {
+        Sphere sp;
+        sp.center = v3(center);
+        sp.radius = radius;
+        sp.material = toMaterial(mat, nullptr, 0, 0);
+        static_cast<HostScene*>(p)->scene.spheres.push_back(sp);
+    });
+}
+
+int rtxh_scene_set_envmap(void* p, const float* rgb, int w, int h, int mapping, float vfovDegrees, const float* bg)
+{
+    return guarded([&] {
+        auto* s = static_cast<HostScene*>(p);
+        auto e = std::make_unique<EnvironmentMap>();
+        if (rgb) {
+            e->texture = std::make_shared<Image>();
+            e->texture->width = w;
+            e->texture->height = h;
+            e->texture->pixels.resize(size_t(w) * size_t(h));
+            std::memcpy(static_cast<void*>(e->texture->pixels.data()), rgb, size_t(w) * size_t(h) * 12);
+        }
+        e->mappingType = mapping == RTX_ENV_SPHERICAL ? SPHERICAL : CYLINDRICAL;
+        e->verticalFieldOfViewDegrees = vfovDegrees;
+        e->backgroundColor = v3(bg);
+        s->envs.push_back(std::move(e));
+        s->scene.environmentMap.assign(1, s->envs.back().get());
+    });
+}
+
+// ---- host-only flattening (no device) ---------------------------------------
+void* rtxh_flatten(void* p, const rtx_features* f)
+{
+    FlatScene* out = nullptr;
+    if (guarded([&] { out = new FlatScene(flattenScene(static_cast<HostScene*>(p)->scene, toFeatures(f))); }))
+        return nullptr;
+    return out;
+}
+void rtxh_flat_free(void* fl) { delete static_cast<FlatScene*>(fl); }
+// out: nodes, tris, textures, texels, materials, lights, spheres, levels, leaves
+void rtxh_flat_counts(const void* fl, int64_t* out)
+{
+    const auto* f = static_cast<const FlatScene*>(fl);
+    out[0] = int64_t(f->nodes.size());
+    out[1] = int64_t(f->tris.size());
+    out[2] = int64_t(f->textures.size());
+    out[3] = int64_t(f->texels.size() / 3);
+    out[4] = int64_t(f->materials.size());
+    out[5] = int64_t(f->lights.size());
+    out[6] = int64_t(f->spheres.size());
+    out[7] = f->numLevels;
+    out[8] = f->numLeaves;
+}
+void rtxh_flat_copy(const void* fl, rtx_node* nodes, rtx_tri* tris, rtx_tri_attr* attrs, rtx_material* mats, rtx_texture* textures, float* texels)
+{
+    const auto* f = static_cast<const FlatScene*>(fl);
+    if (nodes)
+        std::memcpy(nodes, f->nodes.data(), f->nodes.size() * sizeof(rtx_node));
+    if (tris)
+        std::memcpy(tris, f->tris.data(), f->tris.size() * sizeof(rtx_tri));
+    if (attrs)
+        std::memcpy(attrs, f->attrs.data(), f->attrs.size() * sizeof(rtx_tri_attr));
+    if (mats)
+        std::memcpy(mats, f->materials.data(), f->materials.size() * sizeof(rtx_material));
+    if (textures)
+        std::memcpy(textures, f->textures.data(), f->textures.size() * sizeof(rtx_texture));
+    if (texels)
+        std::memcpy(texels, f->texels.data(), f->texels.size() * sizeof(float));
+}
+void rtxh_flat_root(const void* fl, int32_t* ref, float* lo, float* hi)
+{
+    const auto* f = static_cast<const FlatScene*>(fl);
+    *ref = f->rootRef;
+    std::memcpy(lo, f->rootLo, 12);
+    std::memcpy(hi, f->rootHi, 12);
+}
+// the description rtx_scene_create takes, pointing into the FlatScene
+void rtxh_flat_desc(const void* fl, rtx_scene_desc* out) { *out = static_cast<const FlatScene*>(fl)->desc(); }
+
+// ---- GPU-backed objects --------------------------------------------------------
+void* rtxh_bvh_create(void* p, const rtx_features* f)
+{
+    BvhInterface* b = nullptr;
+    if (guarded([&] { b = new BvhInterface(&static_cast<HostScene*>(p)->scene, toFeatures(f)); }))
+        return nullptr;
+    return b;
+}
+void rtxh_bvh_free(void* b) { delete static_cast<BvhInterface*>(b); }
+int rtxh_bvh_levels(const void* b) { return static_cast<const BvhInterface*>(b)->numLevels(); }
+int rtxh_bvh_leaves(const void* b) { return static_cast<const BvhInterface*>(b)->numLeaves(); }
+const void* rtxh_bvh_flat(const void* b) { return &static_cast<const BvhInterface*>(b)->flat(); }
+const void* rtxh_bvh_device_scene(const void* b) { return static_cast<const BvhInterface*>(b)->deviceScene(); }
+
+int rtxh_intersect_batch(const void* b, const rtx_ray* rays, int64_t n, const rtx_features* f, rtx_hit* hits, rtx_stats* stats)
+{
+    return guarded([&] { static_cast<const BvhInterface*>(b)->intersectBatch(rays, size_t(n), hits, toFeatures(f), stats); });
+}
+
+// BvhInterface::intersect for one ray, reported through HitInfo like the reference:
+// out = normal3, bary3, uv2, kd3, ks3, shininess, transparency, triangle indices 3 (as float), mesh index
+int rtxh_intersect_one(const void* b, rtx_ray* ray, const rtx_features* f, float* out, int* hit)
+{
+    return guarded([&] {
+        const auto* bvh = static_cast<const BvhInterface*>(b);
+        Ray r;
+        r.origin = v3(ray->origin);
+        r.direction = v3(ray->direction);
+        r.t = ray->t;
+        HitInfo hi;
+        *hit = bvh->intersect(r, hi, toFeatures(f)) ? 1 : 0;
+        ray->t = r.t;
+        std::memset(out, 0, 20 * sizeof(float));
+        if (*hit) {
+            std::memcpy(out, &hi.normal, 12);
+            std::memcpy(out + 3, &hi.barycentricCoord, 12);
+            std::memcpy(out + 6, &hi.texCoord, 8);
+            std::memcpy(out + 8, &hi.material.kd, 12);
+            std::memcpy(out + 11, &hi.material.ks, 12);
+            out[14] = hi.material.shininess;
+            out[15] = hi.material.transparency;
+            out[16] = float(hi.triangle.x), out[17] = float(hi.triangle.y), out[18] = float(hi.triangle.z);
+            out[19] = hi.mesh ? float(hi.mesh - bvh->scene()->meshes.data()) : -1.f;
+        }
+    });
+}
+
+// any driver, explicit parameters (renderFrame)
+int rtxh_render(const void* b, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* rp, float* out, rtx_stats* stats)
+{
+    return guarded([&] {
+        const auto* bvh = static_cast<const BvhInterface*>(b);
+        Screen screen(ivec2 { rp->width, rp->height });
+        if (rp->tile_world > 1)
+            std::memcpy(static_cast<void*>(screen.pixels().data()), out, size_t(rp->width) * size_t(rp->height) * 12);
+        renderFrame(*bvh, toTrackball(cam, rp->width, rp->height), screen, toFeatures(f), *rp, stats);
+        std::memcpy(out, screen.pixels().data(), size_t(rp->width) * size_t(rp->height) * 12);
+    });
+}
+
+// the reference's five named drivers with their own defaults (src/render.h:18-26)
+int rtxh_render_named(const void* b, const rtx_camera* cam, const rtx_camera* prevCam, const rtx_features* f, int driver, int W, int H, int samples, float aperture,
+    float focal, float* out)
+{
+    return guarded([&] {
+        const auto* bvh = static_cast<const BvhInterface*>(b);
+        const Scene& scene = *bvh->scene();
+        Screen screen(ivec2 { W, H });
+        const Trackball camera = toTrackball(cam, W, H);
+        const Features feat = toFeatures(f);
+        switch (driver) {
+        case RTX_DRIVER_PLAIN:
+            renderRayTracing(scene, camera, *bvh, screen, feat);
+            break;
+        case RTX_DRIVER_TRANSPARENCY:
+            renderRayTracingTransparency(scene, camera, *bvh, screen, feat);
+            break;
+        case RTX_DRIVER_DOF:
+            if (samples > 0)
+                renderRayTracingDepthOfField(scene, camera, *bvh, screen, feat, aperture, focal, samples);
+            else
+                renderRayTracingDepthOfField(scene, camera, *bvh, screen, feat);
+            break;
+        case RTX_DRIVER_MRAYS:
+            if (samples > 0)
+                renderRayTracingMRaysPerPixel(scene, camera, *bvh, screen, feat, samples);
+            else
+                renderRayTracingMRaysPerPixel(scene, camera, *bvh, screen, feat);
+            break;
+        case RTX_DRIVER_MOTION_BLUR: {
+            resetMotionBlur();
+            const Trackball prev = toTrackball(prevCam, W, H);
+            if (samples > 0) {
+                renderRayTracingMotionBlur(scene, prev, *bvh, screen, feat, samples);
+                renderRayTracingMotionBlur(scene, camera, *bvh, screen, feat, samples);
+            } else {
+                renderRayTracingMotionBlur(scene, prev, *bvh, screen, feat);
+                renderRayTracingMotionBlur(scene, camera, *bvh, screen, feat);
+            }
+        } break;
+        default:
+            throw RtError("unknown driver");
+        }
+        std::memcpy(out, screen.pixels().data(), size_t(W) * size_t(H) * 12);
+    });
+}
+
+// camera as the device receives it (derived fields filled in)
+void rtxh_camera(const rtx_camera* cam, int W, int H, rtx_camera* out) { *out = toTrackball(cam, W, H).deviceCamera(); }
+
+void rtxh_set_sampling(int shadowSamples, int glossyRays, uint32_t seed)
+{
+    if (shadowSamples > 0)
+        sampleSize = shadowSamples;
+    if (glossyRays > 0)
+        numberOfRays = glossyRays;
+    samplingSeed = seed;
+}
+
+int rtxh_write_bmp(const float* rgb, int W, int H, const char* path)
+{
+    return guarded([&] {
+        Screen screen(ivec2 { W, H });
+        std::memcpy(static_cast<void*>(screen.pixels().data()), rgb, size_t(W) * size_t(H) * 12);
+        screen.writeBitmapToFile(path);
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,133 @@
+// The reference's hot-path API, backed by the MI355X library.  Same class and
+// function names, argument order and meaning as the reference so that its
+// callers (src/main.cpp:50-63,159,218,226,313,509,546,573) compile against this
+// header unchanged apart from the namespace:
+//
+//   BvhInterface                       src/bvh_interface.h:12-41
+//   Trackball (camera subset)          framework/include/framework/trackball.h:14-59
+//   Screen    (framebuffer subset)     src/screen.h:10-33
+//   renderRayTracing*, getFinalColor   src/render.h:18-29
+//
+// All work runs on the GPU through the C ABI of include/rtx.h.  There is no CPU
+// fallback: if no device can be initialised, BvhInterface's constructor throws.
+#pragma once
+#include <stdexcept>
+#include <string>
+
+#include "bvh_build.h"
+#include "rt_types.h"
+#include "rtx.h"
+
+namespace rt {
+
+// Thrown where the reference would have thrown std::exception or called exit
+// (missing files, bad scene): here also for device errors.
+struct RtError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// Bind the calling thread to a GPU (rtx_init).  BvhInterface's constructor calls
+// selectDevice(0) itself if the thread has not chosen one.
+void selectDevice(int device);
+
+// Process-wide sampling knobs, globals in the reference: sampleSize
+// (src/light.cpp:14) and numberOfRays (src/shading.cpp:9).
+extern int sampleSize;
+extern int numberOfRays;
+// Key of the counter RNG that replaces the reference's std::random_device draws.
+extern uint32_t samplingSeed;
+
+class BvhInterface {
+public:
+    // Builds the tree on the host with the reference's builder, flattens it and
+    // uploads it once.  pScene must outlive the object (as in the reference,
+    // which keeps the raw pointer).
+    BvhInterface(Scene* pScene, const Features& features);
+    BvhInterface(const BvhInterface& other);
+    BvhInterface& operator=(const BvhInterface& other);
+    ~BvhInterface();
+
+    [[nodiscard]] int numLevels() const;
+    [[nodiscard]] int numLeaves() const;
+    // Visual-debug hooks of the reference (OpenGL); no-ops here.
+    void debugDrawLevel(int level);
+    void debugDrawLeaf(int leafIdx);
+
+    // Closest hit of one ray; ray.t is the search limit on entry and the hit
+    // distance on return.  One device launch per call: use intersectBatch for
+    // more than a handful of rays.
+    bool intersect(Ray& ray, HitInfo& hitInfo, const Features& features) const;
+    // n rays at once; hits[i] as rtx_hit (include/rtx.h).  Not in the reference.
+    void intersectBatch(const rtx_ray* rays, size_t n, rtx_hit* hits, const Features& features, rtx_stats* stats = nullptr) const;
+
+    [[nodiscard]] const rtx_scene* deviceScene() const { return m_scene; }
+    [[nodiscard]] const FlatScene& flat() const { return *m_flat; }
+    [[nodiscard]] Scene* scene() const { return m_pScene; }
+
+private:
+    Scene* m_pScene;
+    rtx_scene* m_scene;
+    std::shared_ptr<FlatScene> m_flat;
+};
+
+// Camera state and ray generation of the reference's Trackball
+// (framework/src/trackball.cpp:64-110).  The window is reduced to its aspect
+// ratio (Window::getAspectRatio, framework/src/window.cpp:379-384).
+class Trackball {
+public:
+    Trackball(float aspectRatio, float fovy, float distanceFromLookAt = 4.0f, float rotationX = 0.0f, float rotationY = 0.0f);
+    Trackball(float aspectRatio, float fovy, const vec3& lookAt, float distanceFromLookAt = 4.0f, float rotationX = 0.0f, float rotationY = 0.0f);
+    [[nodiscard]] vec3 position() const;
+    [[nodiscard]] vec3 lookAt() const { return m_lookAt; }
+    [[nodiscard]] vec3 rotationEulerAngles() const { return m_rotationEulerAngles; }
+    [[nodiscard]] float distanceFromLookAt() const { return m_distanceFromLookAt; }
+    void setCamera(const vec3 lookAt, const vec3 rotations, const float dist);
+    [[nodiscard]] Ray generateRay(const vec2& pixel) const;
+    // the plain-data camera the device consumes
+    [[nodiscard]] rtx_camera deviceCamera() const;
+
+private:
+    float m_fovy, m_halfScreenSpaceHeight, m_halfScreenSpaceWidth;
+    vec3 m_lookAt { 0.0f, 0.0f, 0.0f };
+    float m_distanceFromLookAt;
+    vec3 m_rotationEulerAngles { 0.f, 0.f, 0.f };
+};
+
+// fp32 RGB framebuffer in the reference's layout: row 0 is the top row
+// (src/screen.cpp:37-43).
+class Screen {
+public:
+    explicit Screen(const ivec2& resolution, bool presentable = false);
+    void clear(const vec3& color);
+    void setPixel(int x, int y, const vec3& color);
+    [[nodiscard]] ivec2 resolution() const { return m_resolution; }
+    [[nodiscard]] int indexAt(int x, int y) const { return (m_resolution.y - 1 - y) * m_resolution.x + x; }
+    [[nodiscard]] const std::vector<vec3>& pixels() const { return m_textureData; }
+    [[nodiscard]] std::vector<vec3>& pixels() { return m_textureData; }
+    // 4-channel BMP, clamp then truncate to 8 bits (src/screen.cpp:45-56)
+    void writeBitmapToFile(const std::string& filePath) const;
+
+private:
+    ivec2 m_resolution;
+    std::vector<vec3> m_textureData;
+};
+
+// src/render.h:18-29.  `scene` must be the scene the BvhInterface was built from.
+void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features);
+void renderRayTracingTransparency(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features);
+void renderRayTracingDepthOfField(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, float aperture = 0.1f, float focalLength = 2.0f, int samples = 100);
+void renderRayTracingMRaysPerPixel(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, int samples = 64);
+// Stateful like the reference: the first call renders a still frame and
+// remembers the camera; later calls blur between the remembered and the current one.
+void renderRayTracingMotionBlur(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, int steps = 7);
+// Forget the remembered motion-blur camera (the reference never does).
+void resetMotionBlur();
+
+// General form behind the five drivers: any driver with an explicit ray depth
+// (the reference's drivers hard-code 0 or 1), optional interleaved-tile
+// partition, statistics.
+void renderFrame(const BvhInterface& bvh, const Trackball& camera, Screen& screen, const Features& features, rtx_render_params params, rtx_stats* stats = nullptr);
+
+rtx_features toDeviceFeatures(const Features& features);
+
+} // namespace rt

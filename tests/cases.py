@@ -1,0 +1,129 @@
+"""Shared definitions of the parity cases: which scene, camera, features and
+driver parameters each golden image / ray batch was produced with.  Used by
+tests/golden/make_fixtures.py (which runs them through the reference) and by the
+tests (which run them through the oracle and the HIP path).
+"""
+import os
+
+import numpy as np
+
+from raytracer_amd import abi
+from raytracer_amd.scene import SceneData, make_camera, make_params
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# reference SceneType values (src/scene.h:16-29) -> fixture names
+SCENES = {
+    "triangle": 0, "cube": 1, "cube_textured": 2, "cornell": 3, "cornell_parallelogram": 4,
+    "monkey": 5, "teapot": 6, "spheres": 8, "custom": 9, "transparency": 10,
+}
+
+BASE = dict(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
+
+
+def load_scene(name) -> SceneData:
+    return SceneData.load(os.path.join(GOLDEN, "scenes", name + ".npz"))
+
+
+def env_image(seed=3, w=64, h=32):
+    """Seeded stand-in for the equirectangular environment image (the reference's
+    HDR file is not in its checkout; Image quantises to 8 bits anyway)."""
+    rng = np.random.default_rng(seed)
+    return (np.floor(rng.random((h, w, 3)) * 256) / 255.0).astype(np.float32)
+
+
+class Case:
+    def __init__(self, name, scene, features, params, camera=None, ref_mode=0, env=None, lights=None, tol=0.0):
+        self.name, self.scene_name = name, scene
+        self.features = dict(features)
+        self.params = dict(params)
+        self.camera = dict(camera or {})
+        self.ref_mode = ref_mode      # 0: the reference's own driver, 1: harness loop (depth / keyed RNG)
+        self.env = env                # (image, mapping, vfov_degrees, background)
+        self.lights = lights          # replaces the scene's lights
+        self.tol = tol
+
+    def build(self):
+        scene = load_scene(self.scene_name)
+        if self.lights is not None:
+            scene.lights = list(self.lights)
+        if self.env is not None:
+            scene.set_envmap(*self.env)
+        f = abi.features(**self.features)
+        cam = make_camera(**self.camera)
+        p = dict(self.params)
+        prev = p.pop("prev", None)
+        rp = make_params(**p)
+        if prev is not None:
+            rp.prev_camera = make_camera(**prev)
+        return scene, f, cam, rp
+
+
+W = 64
+_ENV = env_image()
+_AREA = [abi.parallelogram_light((-0.2, 0.5, 0.0), (0.4, 0, 0), (0, 0, 0.4), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1))]
+
+IMAGE_CASES = [
+    # BASELINE config 1: Cornell box, 1 spp, point light, hard shadows, one mirror bounce, SAH tree
+    Case("cfg1_cornell", "cornell", dict(BASE, recursive=1), dict(width=128, height=128)),
+    Case("cornell_median_flat", "cornell", dict(shading=1, hard_shadow=1, accel_structure=1), dict(width=W, height=W)),
+    Case("cornell_albedo", "cornell", dict(accel_structure=1), dict(width=W, height=W)),
+    Case("cornell_bruteforce", "cornell", dict(shading=1, hard_shadow=1, normal_interp=1, recursive=1), dict(width=W, height=W)),
+    Case("cornell_noshadow", "cornell", dict(shading=1, normal_interp=1, accel_structure=1, recursive=1), dict(width=W, height=W)),
+    # BASELINE config 2 shape: jittered multi-sample driver, hard shadows
+    Case("monkey_mrays4", "monkey", BASE, dict(width=W, height=W, driver=abi.DRIVER_MRAYS, samples=4)),
+    Case("teapot_mrays16", "teapot", BASE, dict(width=96, height=54, driver=abi.DRIVER_MRAYS, samples=16)),
+    Case("teapot_mrays_default64", "teapot", BASE, dict(width=24, height=16, driver=abi.DRIVER_MRAYS)),
+    Case("monkey_dof5", "monkey", BASE, dict(width=W, height=W, driver=abi.DRIVER_DOF, samples=5)),
+    Case("monkey_dof100", "monkey", BASE, dict(width=16, height=16, driver=abi.DRIVER_DOF, samples=100, aperture=0.2, focal_length=2.5)),
+    Case("transparency_cg3", "transparency", dict(BASE, recursive=1), dict(width=W, height=W, driver=abi.DRIVER_TRANSPARENCY)),
+    Case("monkey_blur3", "monkey", dict(BASE, recursive=1), dict(width=W, height=W, driver=abi.DRIVER_MOTION_BLUR, samples=3, prev=dict(look_at=(0, 0, 0.3))), tol=1e-3),
+    Case("monkey_blur7_rot", "monkey", BASE, dict(width=48, height=48, driver=abi.DRIVER_MOTION_BLUR, samples=7, prev=dict(rotation_degrees=(25, 15, 0))), tol=1e-3),
+    Case("spheres", "spheres", dict(BASE, recursive=1), dict(width=W, height=W), camera=dict(distance=-2.0, rotation_degrees=(0, 0, 0))),
+    # area lights and glossy reflections (keyed RNG; harness-owned pixel loop around getFinalColor)
+    Case("cube_segment_soft", "cube", dict(BASE, soft_shadow=1), dict(width=W, height=W, shadow_samples=8), ref_mode=1),
+    Case("cornell_parallelogram_soft", "cornell_parallelogram", dict(BASE, soft_shadow=1), dict(width=W, height=W, shadow_samples=8), ref_mode=1),
+    # BASELINE config 3 shape: area light + glossy reflections, depth 4
+    Case("cornell_area_glossy_d4", "cornell", dict(BASE, soft_shadow=1, recursive=1, glossy_reflection=1),
+         dict(width=32, height=32, shadow_samples=4, glossy_rays=3, ray_depth=4), ref_mode=1, lights=_AREA),
+    Case("cornell_glossy_d3_mrays", "cornell", dict(BASE, recursive=1, glossy_reflection=1),
+         dict(width=48, height=48, driver=abi.DRIVER_MRAYS, samples=2, glossy_rays=3, ray_depth=3), ref_mode=1),
+    Case("cornell_mirror_d4", "cornell", dict(BASE, recursive=1), dict(width=W, height=W, ray_depth=4), ref_mode=1),
+    # BASELINE config 4 shape: texture filtering and environment map
+    Case("cube_tex_nearest", "cube_textured", dict(BASE, texture_mapping=1), dict(width=W, height=W)),
+    Case("cube_tex_bilinear", "cube_textured", dict(BASE, texture_mapping=1, bilinear_texture_filtering=1), dict(width=W, height=W)),
+    Case("cube_tex_trilinear", "cube_textured", dict(BASE, texture_mapping=1, bilinear_texture_filtering=1, mipmap_texture_filtering=1), dict(width=W, height=W)),
+    Case("quad_tex_trilinear", "custom", dict(BASE, texture_mapping=1, bilinear_texture_filtering=1, mipmap_texture_filtering=1), dict(width=W, height=W),
+         camera=dict(rotation_degrees=(60, 200, 0), distance=4.0), lights=[abi.point_light((0.5, 0.7, 2.0))]),
+    Case("monkey_env_spherical", "monkey", dict(BASE, environment_mapping=1), dict(width=W, height=W), env=(_ENV, abi.ENV_SPHERICAL, 180.0, (0.5, 0.5, 0.5))),
+    Case("monkey_env_cylindrical_bilinear", "monkey", dict(BASE, environment_mapping=1, bilinear_texture_filtering=1, recursive=1), dict(width=W, height=W),
+         env=(_ENV, abi.ENV_CYLINDRICAL, 120.0, (0.5, 0.5, 0.5))),
+]
+
+CASES_BY_NAME = {c.name: c for c in IMAGE_CASES}
+
+
+def ray_batch(scene: SceneData, seed, n_random=1500, grid=48):
+    """Primary rays through a grid of pixel corners plus random rays started inside
+    and outside the scene's bounds, some axis-parallel, some with a finite search
+    limit: the inputs of the ray-batch parity fixtures."""
+    from oracle.bindings import OracleEngine, primary_rays
+    cam = make_camera()
+    rays = [primary_rays(cam, grid, grid)]
+    rng = np.random.default_rng(seed)
+    pts = [m.vertices[:, :3] for m in scene.meshes] + [np.array([c], np.float32) for c, _, _ in scene.spheres]
+    allp = np.concatenate(pts) if pts else np.zeros((1, 3), np.float32)
+    lo, hi = allp.min(0) - 0.5, allp.max(0) + 0.5
+    r = np.zeros(n_random, abi.RAY_DTYPE)
+    r["origin"] = (lo + rng.random((n_random, 3)) * (hi - lo)).astype(np.float32)
+    d = rng.normal(size=(n_random, 3)).astype(np.float32)
+    d[::7, 0] = 0.0       # axis-parallel components: 1/0 = inf in the slab test
+    d[::11, 1] = 0.0
+    d[::13, 2] = 0.0
+    d[np.all(d == 0, axis=1)] = (0, 0, 1)
+    r["direction"] = d
+    r["t"] = np.finfo(np.float32).max
+    r["t"][::5] = rng.random(len(r["t"][::5])).astype(np.float32) * 2.0
+    # rays from surface points towards the light (shadow-ray shaped): start exactly on geometry
+    rays.append(r)
+    return np.concatenate(rays)
