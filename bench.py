@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + secondary) on the dragon scene,
+1920x1080, 16 spp jittered, Phong shading + hard shadows (BASELINE.json
+configs[1]), on 1..8 MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one frame.  The scene, its BVH and the framebuffer live in HBM before
+the timed region starts; nothing crosses PCIe inside it.  With N > 1 the frame
+is cut into interleaved 32x32 tiles (tile t -> rank t % N), every rank renders
+its tiles and the framebuffer is assembled on rank 0 by one RCCL gather per
+frame; total work is fixed, so scaling is "strong".
+
+data/dragon.obj is not part of the reference checkout, so the geometry is the
+seeded stand-in of raytracer_amd.scene.dragon_standin (81 920 triangles, unit
+ball, same light and camera as SceneType::Dragon); pass --obj-npz to use a real
+mesh exported as a scene .npz.
+
+One JSON line is printed by rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def algorithmic_bytes(stats_rays, shaded, pixels, n_aabb, n_tri):
+    """Implementation-neutral bytes one frame must move: per ray 28 B in, 24 B per
+    box test and 36 B per triangle test the reference's visit rule performs, 16 B
+    out; per shaded hit three 32-B vertices and a 32-B material; 12 B per pixel."""
+    return stats_rays * (28.0 + 24.0 * n_aabb + 36.0 * n_tri + 16.0) + shaded * (3 * 32 + 32) + pixels * 12.0
+
+
+def cpu_baseline(scene, features, cam, args):
+    """The CPU path timed on this box's host cores on a bounded sample of the same
+    workload: the reference's own renderRayTracingMRaysPerPixel when oracle/_ref
+    was built and shipped, else the CPU restatement.  Also returns the per-ray
+    work counts of the reference's visit rule (from the instrumented restatement)."""
+    from raytracer_amd import abi
+    from raytracer_amd.scene import make_params
+    from oracle.bindings import OracleEngine, RefEngine, have_ref
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    orc = OracleEngine(scene, features)
+    # per-ray work of the reference's visit rule on a 1/16-area frame of the same view
+    small = make_params(args.width // 4, args.height // 4, driver=abi.DRIVER_MRAYS, samples=args.spp)
+    orc.render(cam, features, small, threads=threads)
+    c = orc.counters.astype(np.float64)
+    rays_small = c[0] + c[1] + c[2]
+    n_aabb, n_tri = c[3] / rays_small, c[4] / rays_small
+    eng = RefEngine(scene, features) if have_ref() else orc
+    kind = eng.kind
+    # probe, then size the sample for roughly 15 s of CPU work
+    t0 = time.perf_counter()
+    eng.render(cam, features, small, threads=threads)
+    probe = time.perf_counter() - t0
+    scale = min(4.0, max(1.0, (15.0 / max(probe, 1e-3)) ** 0.5))
+    w, h = int(small.width * scale) // 8 * 8, int(small.height * scale) // 8 * 8
+    sample = make_params(w, h, driver=abi.DRIVER_MRAYS, samples=args.spp)
+    t0 = time.perf_counter()
+    eng.render(cam, features, sample, threads=threads)
+    dt = time.perf_counter() - t0
+    orc.render(cam, features, sample, threads=threads)
+    rays = float(orc.counters[:3].sum())
+    orc.close()
+    if eng is not orc:
+        eng.close()
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind=kind,
+                sample=f"{w}x{h} frame of the same scene/camera, {args.spp} spp, {int(rays)} rays in {dt:.2f} s "
+                       f"({'reference renderRayTracingMRaysPerPixel, OpenMP' if kind == 'reference' else 'CPU restatement, OpenMP'})"), n_aabb, n_tri
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--obj-npz", default=None, help="scene .npz (raytracer_amd.scene.SceneData.save) to use instead of the stand-in")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import abi, engine
+    from raytracer_amd.scene import SceneData, dragon_scene, make_camera, make_params
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    hip = engine.hip_lib()
+    scene = SceneData.load(args.obj_npz) if args.obj_npz else dragon_scene()
+    features = abi.features(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
+    cam_in = make_camera()
+
+    t_build = time.perf_counter()
+    gpu = engine.GpuEngine(scene, features, device=local_rank)   # host BVH build + flatten + one upload
+    t_build = time.perf_counter() - t_build
+    dscene = gpu.device_scene()
+    cam = engine.device_camera(cam_in, args.width, args.height)
+    rp = make_params(args.width, args.height, driver=abi.DRIVER_MRAYS, samples=args.spp, tile_size=args.tile,
+                     tile_rank=rank, tile_world=world)
+    # queue the library's work on a torch stream so events and collectives order with it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    assert hip.rtx_set_stream(C.c_void_p(stream.cuda_stream)) == 0, hip.rtx_last_error()
+
+    pixels = args.width * args.height
+    frame = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
+    if world > 1:
+        per = hip.rtx_tiles_per_rank(C.byref(rp))
+        tiles = torch.zeros((per, args.tile, args.tile, 3), dtype=torch.float32, device=dev)
+        gathered = torch.zeros((world,) + tuple(tiles.shape), dtype=torch.float32, device=dev) if rank == 0 else None
+        gather_list = list(gathered.unbind(0)) if rank == 0 else None
+
+    def step(stats=None):
+        sp = C.byref(stats) if stats is not None else None
+        if world == 1:
+            rc = hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(frame.data_ptr()), sp)
+        else:
+            rc = hip.rtx_render_tiles_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(tiles.data_ptr()), sp)
+            dist.gather(tiles, gather_list, dst=0)
+            if rank == 0 and rc == 0:
+                rc = hip.rtx_detile_device(C.c_void_p(gathered.data_ptr()), C.byref(rp), C.c_void_p(frame.data_ptr()))
+        if rc != 0:
+            raise RuntimeError(hip.rtx_last_error().decode())
+
+    # one counted frame: rays per frame (deterministic) and this rank's kernel time
+    st = abi.Stats()
+    step(st)
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce, st.shaded_hits], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    rays_frame = float(counts[:3].sum())
+    shaded_frame = float(counts[3])
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps     # HIP events on the launch stream, per frame
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax[0])
+
+    if rank == 0:
+        value = rays_frame * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s (primary+secondary), dragon 1080p 16spp",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"dragon stand-in ({scene.n_triangles} tris, seeded; dragon.obj is absent from the reference checkout) "
+                                   f"{args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light, sweep-split BVH "
+                                   f"({gpu.levels()} levels, {gpu.leaves()} leaves)",
+                       "rays_per_frame": int(rays_frame), "primary": int(counts[0]), "shadow": int(counts[1]),
+                       "partition": "whole frame" if world == 1 else f"interleaved {args.tile}x{args.tile} tiles + RCCL gather to rank 0",
+                       "bvh_build_upload_s": round(t_build, 3)},
+        }
+        if world == 1:
+            cb, n_aabb, n_tri = (None, None, None)
+            if not args.no_cpu_baseline:
+                cb, n_aabb, n_tri = cpu_baseline(scene, features, cam_in, args)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get("bytes_per_launch")
+            if n_aabb is not None:
+                alg = algorithmic_bytes(rays_frame, shaded_frame, pixels, n_aabb, n_tri)
+                achieved = alg / (kernel_ms * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                                   "kernel": "renderKernel", "kernel_ms": round(kernel_ms, 4),
+                                   "algorithmic_bytes_per_launch": int(alg), "box_tests_per_ray": round(n_aabb, 3),
+                                   "tri_tests_per_ray": round(n_tri, 3)}
+            if cb is not None:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    gpu.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -266,6 +266,13 @@ int rtx_detile_device(const float* d_all_tiles, const rtx_render_params* params,
 /* Number of tiles each rank's compact buffer holds (the maximum over ranks). */
 int rtx_tiles_per_rank(const rtx_render_params* params);
 
+/* Queue this thread's GPU work on the caller's HIP stream (a hipStream_t, e.g.
+ * the framework stream the device buffers are produced and consumed on) instead
+ * of the library's own; NULL switches back.  With a stats pointer of NULL the
+ * *_device entry points only enqueue and return, so frames can be pipelined
+ * with the caller's other work on that stream. */
+int rtx_set_stream(void* hip_stream);
+
 /* Block until all work queued by this thread's calls has finished. */
 int rtx_synchronize(void);
 

@@ -593,7 +593,8 @@ void setErr(const char* fmt, ...)
 
 struct DeviceCtx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // stream work is queued on (own or caller's)
+    hipStream_t ownStream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t* workCounter = nullptr;          // device
     unsigned long long* stats = nullptr;      // device, S_COUNT words
@@ -716,12 +717,16 @@ bool wantCounters()
     return e && e[0] == '1';
 }
 
+// With stats == NULL the call only queues work and returns; with stats it waits
+// for the kernel and reads the counters back.
 int fetchStats(DeviceCtx* c, rtx_stats* stats, double t0)
 {
+    if (!stats)
+        return RTX_OK;
     float ms = 0.f;
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    if (stats) {
+    {
         unsigned long long h[S_COUNT];
         HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
         stats->rays_primary = h[S_PRIMARY];
@@ -907,7 +912,8 @@ int rtx_init(int device)
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         c->numCUs = prop.multiProcessorCount;
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
+        c->stream = c->ownStream;
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev1));
         HIP_TRY(hipMalloc((void**)&c->workCounter, 256));
@@ -1100,7 +1106,7 @@ int rtx_trace(const rtx_scene* scene, const rtx_ray* rays, size_t n, rtx_hit* hi
         rc = RTX_ERR_DEVICE;
     }
     rc = rc ? rc : traceImpl(scene, dRays, n, dHits, f, stats, t0);
-    if (!rc && hipMemcpy(hits, dHits, n * sizeof(rtx_hit), hipMemcpyDeviceToHost) != hipSuccess) {
+    if (!rc && (hipStreamSynchronize(g_ctx->stream) != hipSuccess || hipMemcpy(hits, dHits, n * sizeof(rtx_hit), hipMemcpyDeviceToHost) != hipSuccess)) {
         setErr("rtx_trace: hit download failed");
         rc = RTX_ERR_DEVICE;
     }
@@ -1157,7 +1163,7 @@ int rtx_render(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         rc = RTX_ERR_DEVICE;
     }
     rc = rc ? rc : renderImpl(scene, cam, f, p, dOut, false, stats, t0);
-    if (!rc && hipMemcpy(out, dOut, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (!rc && (hipStreamSynchronize(g_ctx->stream) != hipSuccess || hipMemcpy(out, dOut, bytes, hipMemcpyDeviceToHost) != hipSuccess)) {
         setErr("rtx_render: framebuffer download failed");
         rc = RTX_ERR_DEVICE;
     }
@@ -1195,6 +1201,15 @@ int rtx_detile_device(const float* dAllTiles, const rtx_render_params* p, float*
     hipLaunchKernelGGL(detileKernel, dim3(uint32_t((n + block - 1) / block)), dim3(block), 0, g_ctx->stream, dAllTiles, dOut, p->width, p->height, g.ts,
         g.tilesX, g.tilesY, g.world, g.tilesPerRank);
     HIP_TRY(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_set_stream(void* hipStream)
+{
+    if (int rc = checkCtx(nullptr))
+        return rc;
+    std::lock_guard<std::mutex> launchLock(g_ctx->launch);
+    g_ctx->stream = hipStream ? static_cast<hipStream_t>(hipStream) : g_ctx->ownStream;
     return RTX_OK;
 }
 

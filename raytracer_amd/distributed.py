@@ -1,0 +1,63 @@
+"""Multi-GPU frame partition: interleaved image tiles, one process per GPU.
+
+Tile t of the frame (row-major over ceil(W/ts) x ceil(H/ts) tiles) belongs to
+rank t % world.  Every rank renders its tiles into a compact buffer (its k-th
+tile at [k*ts*ts*3, ...), rows top-down), the buffers are gathered to rank 0
+(the only exchange step of the path: W*H*12/world bytes per rank) and scattered
+into the Screen-layout frame.  The scene is replicated on every GPU.
+
+The numpy functions below state the layout on the CPU (used by the gloo tests
+and as documentation); on the GPU the same layout is written by
+rtx_render_tiles_device and undone by rtx_detile_device.
+"""
+import numpy as np
+
+
+def tile_grid(width, height, tile_size):
+    return (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
+
+
+def tiles_per_rank(width, height, tile_size, world):
+    tx, ty = tile_grid(width, height, tile_size)
+    return (tx * ty + world - 1) // world
+
+
+def extract_tiles(frame, tile_size, rank, world):
+    """This rank's compact tile buffer cut from a full Screen-layout frame
+    (h, w, 3); padding outside the frame is 0."""
+    h, w, _ = frame.shape
+    tx, ty = tile_grid(w, h, tile_size)
+    out = np.zeros((tiles_per_rank(w, h, tile_size, world), tile_size, tile_size, 3), frame.dtype)
+    for k, t in enumerate(range(rank, tx * ty, world)):
+        x0, y0 = (t % tx) * tile_size, (t // tx) * tile_size
+        blk = frame[y0:y0 + tile_size, x0:x0 + tile_size]
+        out[k, :blk.shape[0], :blk.shape[1]] = blk
+    return out
+
+
+def assemble_tiles(all_tiles, width, height, tile_size, world):
+    """Inverse of extract_tiles over the rank-major stack of every rank's buffer."""
+    tx, ty = tile_grid(width, height, tile_size)
+    per = tiles_per_rank(width, height, tile_size, world)
+    all_tiles = np.asarray(all_tiles).reshape(world, per, tile_size, tile_size, 3)
+    frame = np.zeros((height, width, 3), all_tiles.dtype)
+    for t in range(tx * ty):
+        x0, y0 = (t % tx) * tile_size, (t // tx) * tile_size
+        blk = all_tiles[t % world, t // world]
+        frame[y0:y0 + tile_size, x0:x0 + tile_size] = blk[:height - y0, :width - x0]
+    return frame
+
+
+def gather_tiles(local_tiles, dst=0):
+    """torch.distributed gather of every rank's compact tile buffer to `dst`
+    (RCCL over xGMI for GPU tensors, gloo for CPU tensors).  Returns the
+    rank-major stack on dst and None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if rank == dst:
+        out = torch.empty((world,) + tuple(local_tiles.shape), dtype=local_tiles.dtype, device=local_tiles.device)
+        dist.gather(local_tiles, list(out.unbind(0)), dst=dst)
+        return out
+    dist.gather(local_tiles, None, dst=dst)
+    return None

@@ -45,6 +45,7 @@ def hip_lib():
             getattr(lib, name).argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.Features), C.POINTER(abi.RenderParams), vp, C.POINTER(abi.Stats)]
         lib.rtx_detile_device.argtypes = [vp, C.POINTER(abi.RenderParams), vp]
         lib.rtx_tiles_per_rank.argtypes = [C.POINTER(abi.RenderParams)]
+        lib.rtx_set_stream.argtypes = [vp]
         _hip = lib
     return _hip
 

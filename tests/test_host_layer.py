@@ -1,0 +1,190 @@
+"""CPU tests of the host side: the flattener builds the reference's tree and the
+device records carry the reference's plane arithmetic; the C-ABI library loads,
+exports every symbol include/rtx.h declares and lays its structs out as the
+ctypes mirrors do; without a GPU the product path fails loudly instead of
+falling back to a CPU implementation.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+from raytracer_amd import abi, engine
+from raytracer_amd.scene import SceneData, dragon_standin, make_camera
+from oracle.bindings import OracleEngine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("scene_name", list(cases.SCENES))
+def test_flattener_builds_the_reference_tree(golden_bvh, scene_name):
+    scene = cases.load_scene(scene_name)
+    for sah in (0, 1):
+        f = abi.features(accel_structure=1, bvh_sah_binning=sah)
+        flat = engine.flatten(scene, f)
+        key = f"{scene_name}_{'sweep' if sah else 'median'}"
+        assert [flat.num_levels, flat.num_leaves] == golden_bvh[key + "_meta"].tolist()
+        leaves, boxes = flat.tree()
+        assert [len(l) for l in leaves] == golden_bvh[key + "_leaf_sizes"].tolist()
+        assert [t for l in leaves for t in l] == golden_bvh[key + "_leaf_tris"].tolist()
+        assert np.array_equal(bits(boxes), bits(golden_bvh[key + "_boxes"]))
+        # leaf-ordered records: every triangle exactly once, leaf ends flagged
+        assert sorted(flat.tris["id"].tolist()) == list(range(scene.n_triangles))
+        assert int((flat.tris["flags"] & 1).sum()) == flat.num_leaves
+        flat.close()
+
+
+def test_triangle_records_carry_the_reference_plane():
+    """n and D of every record equal what intersectRayWithTriangle computes per test
+    (src/intersect.cpp:50-58); degenerate triangles are encoded as NaN planes."""
+    scene = cases.load_scene("monkey")
+    # add a degenerate triangle (collinear) and a repeated-vertex one
+    m = scene.meshes[0]
+    nv = len(m.vertices)
+    extra_v = np.zeros((3, 8), np.float32)
+    extra_v[:, :3] = [[0, 0, 0], [0.5, 0.5, 0.5], [1, 1, 1]]
+    scene.meshes[0] = type(m)(np.concatenate([m.vertices, extra_v]), np.concatenate([m.triangles, [[nv, nv + 1, nv + 2], [nv, nv, nv + 1]]]).astype(np.uint32), m.material)
+    flat = engine.flatten(scene, abi.features(accel_structure=1))
+    E = OracleEngine.__new__(OracleEngine)
+    ray = np.zeros(1, abi.RAY_DTYPE)
+    checked = 0
+    for rec in flat.tris[:: max(1, len(flat.tris) // 200)]:
+        c = (rec["v0"] + rec["v1"] + rec["v2"]) / 3
+        ray["origin"], ray["direction"], ray["t"] = c + rec["n"], -rec["n"], np.finfo(np.float32).max
+        hit, t, bary, n = E.kat_triangle(rec["v0"], rec["v1"], rec["v2"], ray[0])
+        if hit:
+            assert np.array_equal(bits(n), bits(rec["n"]))
+            checked += 1
+    assert checked > 100
+    degenerate = flat.tris[flat.tris["id"] >= scene.n_triangles - 2]
+    assert len(degenerate) == 2 and np.isnan(degenerate["n"]).all() and np.isnan(degenerate["d"]).all()
+    flat.close()
+
+
+def test_textures_are_flattened_with_their_mip_chains(golden_kat):
+    scene = cases.load_scene("cube_textured")
+    flat = engine.flatten(scene, abi.features(accel_structure=1))
+    assert flat.n_textures == 1
+    t = flat.textures[0]
+    sizes = golden_kat["mip_default_sizes"]
+    assert t.levels == len(sizes)
+    for l in range(t.levels):
+        assert [t.width[l], t.height[l]] == sizes[l].tolist()
+        px = flat.texels[t.offset[l]: t.offset[l] + t.count[l]]
+        assert np.array_equal(bits(px), bits(golden_kat[f"mip_default_level{l}"]))
+    assert flat.materials["texture"].max() == 0
+    flat.close()
+
+
+def test_empty_scene_and_single_triangle():
+    s = SceneData()
+    flat = engine.flatten(s, abi.features(accel_structure=1))
+    assert flat.root_ref == -2 ** 31 and len(flat.nodes) == 0 and len(flat.tris) == 0 and flat.num_levels == 0
+    flat.close()
+    flat = engine.flatten(cases.load_scene("triangle"), abi.features(accel_structure=1))
+    assert flat.root_ref == -1 and len(flat.nodes) == 0 and flat.num_levels == 1 and flat.num_leaves == 1  # root is a leaf
+    flat.close()
+
+
+def test_bad_triangle_index_is_rejected():
+    s = SceneData()
+    with pytest.raises(ValueError):
+        s.add_mesh(np.zeros((3, 8), np.float32), [[0, 1, 3]])
+
+
+def test_scene_npz_round_trip_and_seeded_standin(tmp_path):
+    a = cases.load_scene("cornell_parallelogram")
+    a.set_envmap(cases.env_image(), abi.ENV_CYLINDRICAL, 120.0, (0.1, 0.2, 0.3))
+    a.add_sphere((1, 2, 3), 0.5, (1, 0, 0, 0, 0, 0, 1, 1))
+    a.save(tmp_path / "s.npz")
+    b = SceneData.load(tmp_path / "s.npz")
+    for k, v in a.to_arrays().items():
+        assert np.array_equal(v, b.to_arrays()[k]), k
+    m1, m2 = dragon_standin(seed=1, subdivisions=3), dragon_standin(seed=1, subdivisions=3)
+    assert np.array_equal(m1.vertices, m2.vertices) and len(m1.triangles) == 20 * 4 ** 3
+    assert abs(np.linalg.norm(m1.vertices[:, :3], axis=1).max() - 1.0) < 1e-5
+    assert not np.array_equal(m1.vertices, dragon_standin(seed=2, subdivisions=3).vertices)
+
+
+# ---- the C ABI ---------------------------------------------------------------
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rtx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtx_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = engine.hip_lib()
+    names = declared_symbols()
+    assert {"rtx_init", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace", "rtx_trace_device", "rtx_render", "rtx_render_device",
+            "rtx_render_tiles_device", "rtx_detile_device", "rtx_tiles_per_rank", "rtx_set_stream", "rtx_synchronize", "rtx_last_error",
+            "rtx_scene_retain"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/rtx.h but not exported"
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    src = tmp_path / "sizes.c"
+    structs = ["rtx_features", "rtx_ray", "rtx_hit", "rtx_node", "rtx_tri", "rtx_tri_attr", "rtx_material", "rtx_texture", "rtx_light",
+               "rtx_sphere", "rtx_envmap", "rtx_scene_desc", "rtx_camera", "rtx_render_params", "rtx_stats"]
+    body = "\n".join(f'    printf("%zu\\n", sizeof({s}));' for s in structs)
+    src.write_text('#include <stdio.h>\n#include "rtx.h"\nint main(void) {\n' + body + "\n    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    mirrors = [C.sizeof(abi.Features), abi.RAY_DTYPE.itemsize, abi.HIT_DTYPE.itemsize, abi.NODE_DTYPE.itemsize, abi.TRI_DTYPE.itemsize,
+               abi.TRI_ATTR_DTYPE.itemsize, abi.MATERIAL_DTYPE.itemsize, C.sizeof(abi.Texture), C.sizeof(abi.Light), abi.SPHERE_DTYPE.itemsize,
+               C.sizeof(abi.EnvMap), C.sizeof(abi.SceneDesc), C.sizeof(abi.Camera), C.sizeof(abi.RenderParams), C.sizeof(abi.Stats)]
+    assert sizes == mirrors, list(zip(structs, sizes, mirrors))
+    assert sizes[3] == sizes[4] == sizes[5] == 64   # node / triangle / attribute records are one 64-byte line each
+
+
+def test_tile_partition_arithmetic():
+    lib = engine.hip_lib()
+    from raytracer_amd.scene import make_params
+    from raytracer_amd.distributed import tiles_per_rank
+    for (w, h, ts, world) in ((1920, 1080, 32, 8), (100, 70, 16, 3), (8, 8, 8, 2), (3840, 2160, 64, 4)):
+        rp = make_params(w, h, tile_size=ts, tile_rank=0, tile_world=world)
+        assert lib.rtx_tiles_per_rank(C.byref(rp)) == tiles_per_rank(w, h, ts, world)
+    bad = make_params(64, 64, tile_size=12)
+    assert lib.rtx_tiles_per_rank(C.byref(bad)) < 0 and b"multiple of 8" in lib.rtx_last_error()
+
+
+def test_no_gpu_means_loud_failure_not_a_cpu_fallback():
+    """Runs in a child process so the GPU state of this one is untouched.  On a
+    machine without a GPU rtx_init fails and so does every product entry point; on
+    a machine with one this test only checks the not-initialised error path."""
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from raytracer_amd import abi, engine
+import cases
+lib = engine.hip_lib()
+f = abi.features(accel_structure=1)
+st = abi.Stats()
+rc = lib.rtx_trace(None, None, 0, None, C.byref(f), C.byref(st))
+assert rc == -4 and b"rtx_init" in lib.rtx_last_error(), (rc, lib.rtx_last_error())
+rc = lib.rtx_init(0)
+if rc != 0:
+    assert lib.rtx_last_error() != b""
+    try:
+        engine.GpuEngine(cases.load_scene("cube"), f)
+    except RuntimeError as e:
+        print("LOUD", e)
+    else:
+        raise SystemExit("GpuEngine worked without a GPU: something fell back to the CPU")
+else:
+    print("GPU present")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "LOUD" in out.stdout or "GPU present" in out.stdout
