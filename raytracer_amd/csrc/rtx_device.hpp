@@ -121,6 +121,28 @@ RTX_DEV bool childTest(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float& key)
     return in || s;
 }
 
+// The same visit rule for a ray whose three reciprocal direction components are
+// finite: no product can be NaN then, so ordering each axis pair with min/max,
+// taking first = max(0, entries) and second = min(exits), and rejecting on
+// first > second gives bit for bit the reference's running comparisons; and
+// lo <= o <= hi is read off the signs of the differences already computed.
+RTX_DEV bool childTestFinite(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float& key)
+{
+    const float dlx = lo.x - o.x, dly = lo.y - o.y, dlz = lo.z - o.z;
+    const float dhx = hi.x - o.x, dhy = hi.y - o.y, dhz = hi.z - o.z;
+    const float t0x = dlx * inv.x, t1x = dhx * inv.x;
+    const float t0y = dly * inv.y, t1y = dhy * inv.y;
+    const float t0z = dlz * inv.z, t1z = dhz * inv.z;
+    float first = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+    const float second = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    const bool miss = first > second;
+    if (first <= 0.0f)
+        first = second;
+    const bool in = fmaxf(fmaxf(dlx, dly), dlz) <= 0.0f && fminf(fminf(dhx, dhy), dhz) >= 0.0f;
+    key = in ? 0.0f : first;
+    return in || (!miss && !(tmax < first));
+}
+
 // Ray/triangle, src/intersect.cpp:32-89, with the plane (n, D) precomputed on
 // the host by the same arithmetic (src/intersect.cpp:50-58).  A degenerate
 // triangle carries NaN in n and D, which fails `t < tmax` below just as the
@@ -228,18 +250,30 @@ struct TraceCounters {
 // and the test order differs).
 // On return t is the closest distance (unchanged on a miss) and bestK the
 // leaf-order record index of the hit triangle (-1 on a miss).
-template <int STACK, bool COUNT>
-RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, float& t, int& bestK, TraceCounters& tc)
+// With EARLY the walk stops as soon as any hit closer than tStop is known (used
+// by shadow queries, for which such a hit already decides the answer), and the
+// triangle search limit may have been shortened by the caller: rootLimit is the
+// unshortened limit, which the root box test must see.
+template <int STACK, bool COUNT, bool EARLY = false>
+RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, float& t, int& bestK, TraceCounters& tc, float tStop = 0.f, float rootLimit = 0.f)
 {
     bestK = -1;
     if (sc.rootRef == kEmptyRoot)
         return;
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // an axis-parallel ray (1/0 = inf) can produce 0 * inf = NaN in the slab test
+    // and must take the comparison-by-comparison form
+    const bool finiteInv = fabsf(inv.x) < __builtin_inff() && fabsf(inv.y) < __builtin_inff() && fabsf(inv.z) < __builtin_inff();
     {
+        // The root box is tested with the plain slab routine, which reports the EXIT
+        // distance for an origin inside the box and rejects when the search limit is
+        // below it (src/intersect.cpp:149-153, src/bounding_volume_hierarchy.cpp:369-377).
+        // A shadow query whose limit was shortened must therefore test the root with
+        // the limit the reference had at that point (rootLimit), not the shortened one.
         float key;
         if (COUNT)
             tc.boxTests++;
-        if (!slab(mk(sc.rootLo), mk(sc.rootHi), o, inv, t, key))
+        if (!slab(mk(sc.rootLo), mk(sc.rootHi), o, inv, EARLY ? rootLimit : t, key))
             return;
     }
     int sp = 0;
@@ -252,8 +286,14 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
             float k0, k1;
             if (COUNT)
                 tc.boxTests += 2;
-            const bool h0 = childTest(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), o, inv, t, k0);
-            const bool h1 = childTest(mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), o, inv, t, k1);
+            bool h0, h1;
+            if (finiteInv) {
+                h0 = childTestFinite(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), o, inv, t, k0);
+                h1 = childTestFinite(mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), o, inv, t, k1);
+            } else {
+                h0 = childTest(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), o, inv, t, k0);
+                h1 = childTest(mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), o, inv, t, k1);
+            }
             const int32_t r0 = __float_as_int(e.x), r1 = __float_as_int(e.y);
             if (h0 && h1) {
                 const bool firstIs1 = k1 < k0;
@@ -282,6 +322,8 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
                     break;
                 k++;
             }
+            if (EARLY && t < tStop)
+                return;
         }
         // pop the next node that is still worth visiting
         have = false;
@@ -326,35 +368,82 @@ struct Hit {
     V3 bary;
 };
 
-// One BvhInterface::intersect: spheres first (src/bounding_volume_hierarchy.cpp:327-328),
-// then triangles, then the winner's attributes (src/bounding_volume_hierarchy.cpp:277-295,
-// src/interpolate.cpp:4-23).
-template <int STACK, bool COUNT>
-RTX_DEV bool intersectScene(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, V3 o, V3 d, float& t, Hit& hit, TraceCounters& tc)
+// Closest hit of one BvhInterface::intersect: spheres first
+// (src/bounding_volume_hierarchy.cpp:327-328), then the triangles.  t is the
+// search limit on entry and the hit distance on return; bestK is the leaf-order
+// record of the winning triangle (-1 if none), sphere the index of the sphere
+// that holds the hit when no triangle beat it (-1 if none).
+// With EARLY, `clip` shortens the triangle search (never the sphere tests, whose
+// acceptance rule compares the limit with the FAR root, src/intersect.cpp:107-119)
+// and tStop ends it at the first hit below it; both are for shadow queries.
+template <int STACK, bool COUNT, bool EARLY = false>
+RTX_DEV bool closestHit(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, V3 o, V3 d, float& t, int& bestK, int& sphere, V3& sphereN, TraceCounters& tc, float tStop = 0.f, float clip = 0.f)
 {
-    bool any = false;
+    sphere = -1;
+    sphereN = mk(0, 0, 0);
+    for (int i = 0; i < sc.nSpheres; i++) {
+        V3 n;
+        if (sphereTest(sc.spheres[i], o, d, t, n)) {
+            sphereN = n;
+            sphere = i;
+        }
+    }
+    const float afterSpheres = t;
+    if (EARLY)
+        t = (clip < t) ? clip : t;
+    if (f.enable_accel_structure)
+        traverseBvh<STACK, COUNT, EARLY>(sc, st, o, d, t, bestK, tc, tStop, afterSpheres);
+    else
+        traverseAll<COUNT>(sc, o, d, t, bestK, tc);
+    return bestK >= 0 || sphere >= 0;
+}
+
+// testVisibilityLightSample, src/light.cpp:70-102: 1 if the light sample at `pos`
+// sees the shading point `hp`, else 0.  The reference shoots a ray from the
+// sample towards the point (direction hp - pos, so the point sits at t ~ 1),
+// takes its closest hit over all distances and calls the sample visible iff
+// that hit lies within 1e-3 of the point; a ray that hits nothing counts as
+// blocked; a sample behind the (viewer-side) surface is blocked whatever the ray
+// finds.  Three shortcuts below give the same answer with less traversal:
+//  - the facing test needs no ray at all;
+//  - when the sample is at least 0.2 away, nothing at t >= 1.01 can be within
+//    1e-3 of the point (0.01 * 0.2 = 2e-3), and "no hit below 1.01" is blocked
+//    either way, so the search is limited to t < 1.01;
+//  - any hit at t < 1 - 4e-3/|hp - pos| is farther than 1e-3 from the point and so
+//    is every hit before it, so the walk may stop there.
+// The margins (2x and 4x) dwarf fp32 rounding for coordinates up to 64; beyond
+// that the query runs unshortened.
+template <int STACK, bool COUNT>
+RTX_DEV float lightVisibility(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, V3 pos, V3 hp, V3 visN, TraceCounters& tc)
+{
+    if (dot(normalize(pos - hp), normalize(visN)) < -1e-6f)
+        return 0.0f;
+    const V3 sd = hp - pos;
+    const float len = length(sd);
+    const float scale = fmaxf(fmaxf(fmaxf(fabsf(hp.x), fabsf(hp.y)), fabsf(hp.z)), fmaxf(fmaxf(fabsf(pos.x), fabsf(pos.y)), fabsf(pos.z)));
+    float ts = kFltMax, clip = kFltMax, tStop = -__builtin_inff();
+    if (len >= 0.2f && scale <= 64.0f) {
+        clip = 1.01f;
+        tStop = 1.0f - 4e-3f / len;
+    }
+    int bk, sph;
+    V3 sn;
+    closestHit<STACK, COUNT, true>(sc, st, f, pos, sd, ts, bk, sph, sn, tc, tStop, clip);
+    const V3 second = pos + ts * sd;
+    return (double(distance(hp, second)) > 1e-3) ? 0.0f : 1.0f;
+}
+
+// HitInfo of the winner (src/bounding_volume_hierarchy.cpp:277-295,
+// src/interpolate.cpp:4-23; spheres: src/intersect.cpp:120-123)
+RTX_DEV void hitAttributes(const DScene& sc, const rtx_features& f, V3 o, V3 d, float t, int bestK, int sphere, V3 sphereN, Hit& hit)
+{
     hit.k = -1;
     hit.material = -1;
     hit.id = RTX_TRI_NONE;
     hit.normal = mk(0, 0, 0);
     hit.bary = mk(0, 0, 0);
     hit.u = hit.v = 0.f;
-    for (int i = 0; i < sc.nSpheres; i++) {
-        V3 n;
-        if (sphereTest(sc.spheres[i], o, d, t, n)) {
-            any = true;
-            hit.normal = n;
-            hit.material = sc.spheres[i].material;
-            hit.id = -2 - i;
-        }
-    }
-    int bestK;
-    if (f.enable_accel_structure)
-        traverseBvh<STACK, COUNT>(sc, st, o, d, t, bestK, tc);
-    else
-        traverseAll<COUNT>(sc, o, d, t, bestK, tc);
     if (bestK >= 0) {
-        any = true;
         const TriRec tr = loadTri(sc, bestK);
         const float4* ap = sc.attrs + size_t(bestK) * 4;
         const float4 a = ap[0], b = ap[1], c = ap[2], e = ap[3];
@@ -372,7 +461,20 @@ RTX_DEV bool intersectScene(const DScene& sc, LaneStack<STACK>& st, const rtx_fe
         hit.k = bestK;
         hit.material = tr.material;
         hit.id = tr.id;
+    } else if (sphere >= 0) {
+        hit.normal = sphereN;
+        hit.material = sc.spheres[sphere].material;
+        hit.id = -2 - sphere;
     }
+}
+
+template <int STACK, bool COUNT>
+RTX_DEV bool intersectScene(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, V3 o, V3 d, float& t, Hit& hit, TraceCounters& tc)
+{
+    int bestK, sphere;
+    V3 sphereN;
+    const bool any = closestHit<STACK, COUNT>(sc, st, f, o, d, t, bestK, sphere, sphereN, tc);
+    hitAttributes(sc, f, o, d, t, bestK, sphere, sphereN, hit);
     return any;
 }
 

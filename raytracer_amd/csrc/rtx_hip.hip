@@ -26,15 +26,31 @@ using namespace rtxd;
 
 namespace {
 
+// Register budget of the render kernels as waves per SIMD: the lean kernel
+// (point lights + hard shadows) fits 128 VGPRs, i.e. 4 waves; the full one is left
+// to the compiler.
+#ifndef RTX_LEAN_WAVES
+#define RTX_LEAN_WAVES 4
+#endif
+#ifndef RTX_FULL_WAVES
+#define RTX_FULL_WAVES 1
+#endif
 constexpr int kMaxDepth = 8;    // frames of the reflection recursion kept per lane
 constexpr int kMaxLayers = 16;  // transparent layers along one camera ray
 
 // ------------------------------------------------------------ statistics ----
 enum { S_PRIMARY = 0, S_SHADOW, S_BOUNCE, S_BOX, S_TRI, S_SHADED, S_COUNT };
 
+// Ray counters are kept per wave (a ballot's population count is the same in
+// every lane, so they live in scalar registers); the optional per-lane box /
+// triangle test counters are summed across the wave at the end.
 struct LaneCounters {
     uint32_t primary = 0, shadow = 0, bounce = 0, shaded = 0;
     TraceCounters tc { 0, 0 };
+    RTX_DEV void countPrimary(bool lane) { primary += __popcll(__ballot(lane)); }
+    RTX_DEV void countShadow(bool lane) { shadow += __popcll(__ballot(lane)); }
+    RTX_DEV void countBounce(bool lane) { bounce += __popcll(__ballot(lane)); }
+    RTX_DEV void countShaded(bool lane) { shaded += __popcll(__ballot(lane)); }
 };
 
 RTX_DEV uint64_t waveSum(uint32_t v)
@@ -48,17 +64,16 @@ RTX_DEV uint64_t waveSum(uint32_t v)
 template <bool COUNT>
 RTX_DEV void flushCounters(const LaneCounters& c, unsigned long long* stats)
 {
-    const uint64_t p = waveSum(c.primary), s = waveSum(c.shadow), b = waveSum(c.bounce), sh = waveSum(c.shaded);
     uint64_t bx = 0, tr = 0;
     if (COUNT) {
         bx = waveSum(c.tc.boxTests);
         tr = waveSum(c.tc.triTests);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&stats[S_PRIMARY], (unsigned long long)p);
-        atomicAdd(&stats[S_SHADOW], (unsigned long long)s);
-        atomicAdd(&stats[S_BOUNCE], (unsigned long long)b);
-        atomicAdd(&stats[S_SHADED], (unsigned long long)sh);
+        atomicAdd(&stats[S_PRIMARY], (unsigned long long)c.primary);
+        atomicAdd(&stats[S_SHADOW], (unsigned long long)c.shadow);
+        atomicAdd(&stats[S_BOUNCE], (unsigned long long)c.bounce);
+        atomicAdd(&stats[S_SHADED], (unsigned long long)c.shaded);
         if (COUNT) {
             atomicAdd(&stats[S_BOX], (unsigned long long)bx);
             atomicAdd(&stats[S_TRI], (unsigned long long)tr);
@@ -66,13 +81,15 @@ RTX_DEV void flushCounters(const LaneCounters& c, unsigned long long* stats)
     }
 }
 
-// one work unit per call, wave-uniform
-RTX_DEV uint32_t fetchUnit(uint32_t* counter)
+// Work fetch, wave-uniform: one atomic claims `chunk` consecutive units.  A single
+// counter word serves only ~90 fetches per microsecond chip-wide, so a frame of
+// half a million 64-lane units must not pay one atomic each.
+RTX_DEV uint32_t fetchUnits(uint32_t* counter, uint32_t chunk)
 {
     uint32_t u = 0;
     if ((threadIdx.x & 63) == 0)
-        u = atomicAdd(counter, 1u);
-    return __shfl(u, 0, 64);
+        u = atomicAdd(counter, chunk);
+    return __builtin_amdgcn_readfirstlane(u);
 }
 
 // ---------------------------------------------------------- trace kernel ----
@@ -82,7 +99,7 @@ struct TraceArgs {
     const rtx_ray* rays;
     rtx_hit* hits;
     uint64_t n;
-    uint32_t nUnits;
+    uint32_t nUnits, chunk;
     uint32_t* workCounter;
     unsigned long long* stats;
 };
@@ -96,15 +113,17 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceArgs A)
     LaneCounters lc;
     const int lane = threadIdx.x & 63;
     for (;;) {
-        const uint32_t unit = fetchUnit(A.workCounter);
-        if (unit >= A.nUnits)
+        const uint32_t first = fetchUnits(A.workCounter, A.chunk);
+        if (first >= A.nUnits)
             break;
+        const uint32_t last = min(first + A.chunk, A.nUnits);
+        for (uint32_t unit = first; unit < last; unit++) {
         const uint64_t i = uint64_t(unit) * 64 + lane;
+        lc.countPrimary(i < A.n);
         if (i < A.n) {
             const rtx_ray r = A.rays[i];
             float t = r.t;
             Hit h;
-            lc.primary++;
             const bool any = intersectScene<STACK, COUNT>(A.sc, st, A.f, mk(r.origin), mk(r.direction), t, h, lc.tc);
             rtx_hit o;
             o.t = t;
@@ -115,6 +134,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceArgs A)
             o.material = any ? h.material : -1;
             o.hit = any ? 1 : 0;
             A.hits[i] = o;
+        }
         }
     }
     flushCounters<COUNT>(lc, A.stats);
@@ -136,9 +156,13 @@ struct RenderArgs {
     // sequence x lanesPerPixel samples, repeated `rounds` times when a pixel has
     // more than 64 samples
     int32_t pixelsPerUnit, lanesPerPixel, rounds;
-    uint32_t nUnits;
+    uint32_t nUnits, chunk;
     uint32_t* workCounter;
     unsigned long long* stats;
+    // skip-ahead tables of the driver-level engine: its state before sample s of
+    // pixel (x, y) is jumpX[x] * jumpY[y] * jumpS[s] mod 2^31-1
+    const uint32_t *jumpX, *jumpY, *jumpS;
+    int32_t jumpSamples; // entries of jumpS
 };
 
 // q-th pixel of this rank's tile sequence: tiles in rank order, 8x8 blocks
@@ -165,6 +189,14 @@ RTX_DEV bool pixelOfSequence(const RenderArgs& A, uint64_t q, int& x, int& yTop,
         return false;
     outIndex = A.compact ? (uint64_t(k) * tilePixels + uint64_t(ly) * ts + lx) : (uint64_t(yTop) * A.W + x);
     return true;
+}
+
+// state of the driver-level engine before the first draw of `sample` of pixel (x, y)
+RTX_DEV uint64_t driverRngState(const RenderArgs& A, int x, int y, uint32_t pixelIndex, int sample, int drawsPerSample)
+{
+    if (sample < A.jumpSamples)
+        return mulMod(mulMod(A.jumpX[x], A.jumpY[y]), A.jumpS[sample]);
+    return minstdAt((uint64_t(pixelIndex) * uint64_t(A.samples) + uint64_t(sample)) * uint64_t(drawsPerSample));
 }
 
 struct Frame { // one suspended getFinalColor call (src/render.cpp:16-66)
@@ -208,18 +240,29 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     bool lastLayer = true;
     V3 nextLayerO = mk(0, 0, 0);
 
+    // shadow query in flight: search limit, early-stop distance and whether the
+    // light sample is behind the surface (then no traversal is needed); see
+    // lightVisibility in rtx_device.hpp for why these leave the answer unchanged
+    float shadowLimit = kFltMax, shadowStop = -__builtin_inff();
+    bool shadowBehind = false;
+
+    bool shadedPending = false; // counted at the loop head, where the wave is converged
     while (__any(state != PS_DONE)) {
         float t = kFltMax;
         Hit hit;
         bool any = false;
-        if (state != PS_DONE) {
-            if (state == PS_SHADOW)
-                lc.shadow++;
-            else if (level == 0)
-                lc.primary++;
-            else
-                lc.bounce++;
-            any = intersectScene<STACK, COUNT>(sc, st, f, ro, rd, t, hit, lc.tc);
+        lc.countShaded(shadedPending);
+        shadedPending = false;
+        lc.countShadow(state == PS_SHADOW);
+        lc.countPrimary(state == PS_RADIANCE && level == 0);
+        lc.countBounce(state == PS_RADIANCE && level != 0);
+        {
+            int bestK = -1, sphere = -1;
+            V3 sphereN = mk(0, 0, 0);
+            if (state == PS_RADIANCE || (state == PS_SHADOW && !shadowBehind))
+                any = closestHit<STACK, COUNT, true>(sc, st, f, ro, rd, t, bestK, sphere, sphereN, lc.tc, state == PS_SHADOW ? shadowStop : -__builtin_inff(), state == PS_SHADOW ? shadowLimit : kFltMax);
+            if (state == PS_RADIANCE)
+                hitAttributes(sc, f, ro, rd, t, bestK, sphere, sphereN, hit);
         }
         if (state == PS_DONE)
             continue;
@@ -232,7 +275,7 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
             // and must end within 1e-3 of it; a ray that hits nothing counts as blocked
             const V3 second = ro + t * rd;
             float vis = 1.0f;
-            if (dot(normalize(samplePos - hp), normalize(visN)) < -1e-6f)
+            if (shadowBehind)
                 vis = 0.0f;
             else if (double(distance(hp, second)) > 1e-3)
                 vis = 0.0f;
@@ -275,7 +318,7 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                     Lo = mk(m.kd);
                     phase = PH_AFTER_LIGHTS;
                 } else {
-                    lc.shaded++;
+                    shadedPending = true;
                     albedo = FULL ? albedoOf(sc, f, m, Ro, Rd, hit) : mk(m.kd);
                     visN = (dot(normalize(hitN), normalize(Ro - hp)) < -1e-6f) ? -hitN : hitN;
                     Lo = mk(0, 0, 0);
@@ -333,6 +376,14 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                     samplePos = pos;
                     ro = pos;
                     rd = hp - pos;
+                    shadowBehind = dot(normalize(pos - hp), normalize(visN)) < -1e-6f;
+                    {
+                        const float len = length(rd);
+                        const float scale = fmaxf(fmaxf(fmaxf(fabsf(hp.x), fabsf(hp.y)), fabsf(hp.z)), fmaxf(fmaxf(fabsf(pos.x), fabsf(pos.y)), fabsf(pos.z)));
+                        const bool shorten = len >= 0.2f && scale <= 64.0f;
+                        shadowLimit = shorten ? 1.01f : kFltMax;
+                        shadowStop = shorten ? 1.0f - 4e-3f / len : -__builtin_inff();
+                    }
                     state = PS_SHADOW;
                     launched = true;
                     break;
@@ -439,118 +490,195 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
             }
         }
     }
+    lc.countShaded(shadedPending);
+    return result;
+}
+
+// The same sample when nothing but point lights, Phong shading and hard shadows
+// are in play (no reflection, area light, texture, environment or transparency):
+// straight-line code with one traversal for the camera ray and one per point
+// light, which keeps far fewer values alive across the traversal loops than the
+// general state machine above.
+template <int STACK, bool COUNT>
+RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, bool active, LaneCounters& lc)
+{
+    const DScene& sc = A.sc;
+    const rtx_features& f = A.f;
+    V3 result = mk(0, 0, 0); // a miss is black without environment mapping (src/render.cpp:61-64)
+    float t = kFltMax;
+    Hit hit;
+    bool any = false;
+    lc.countPrimary(active);
+    if (active)
+        any = intersectScene<STACK, COUNT>(sc, st, f, o, d, t, hit, lc.tc);
+    const bool shade = any && f.enable_shading;
+    lc.countShaded(shade);
+    V3 hp = mk(0, 0, 0), hitN = mk(0, 0, 0), albedo = mk(0, 0, 0), ks = mk(0, 0, 0), visN = mk(0, 0, 0);
+    float shin = 1.f;
+    if (any) {
+        const rtx_material& m = sc.mats[hit.material];
+        result = mk(m.kd); // shading disabled: the albedo (src/light.cpp:184-188)
+        hp = o + t * d;
+        hitN = hit.normal;
+        albedo = mk(m.kd);
+        ks = mk(m.ks);
+        shin = m.shininess;
+        // testVisibilityLightSample's viewer-side normal (src/light.cpp:72-77)
+        visN = (dot(normalize(hitN), normalize(o - hp)) < -1e-6f) ? -hitN : hitN;
+    }
+    if (shade)
+        result = mk(0, 0, 0);
+    for (int li = 0; li < sc.nLights; li++) {
+        const rtx_light& L = sc.lights[li];
+        if (L.type != RTX_LIGHT_POINT)
+            continue; // segment / parallelogram lights only count with soft shadows (src/light.cpp:154,167)
+        const V3 pos = mk(L.p[0]);
+        V3 sh = mk(0, 0, 0);
+        if (shade)
+            sh = phong(pos, mk(L.c[0]), hp, d, hitN, albedo, ks, shin);
+        if (f.enable_hard_shadow) {
+            // src/light.cpp:70-102
+            lc.countShadow(shade);
+            if (shade)
+                sh = sh * lightVisibility<STACK, COUNT>(sc, st, f, pos, hp, visN, lc.tc);
+        }
+        if (shade)
+            result = result + sh;
+    }
     return result;
 }
 
 template <int STACK, bool COUNT, bool FULL>
-__global__ void __launch_bounds__(kBlock) renderKernel(RenderArgs A)
+__global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES) renderKernel(RenderArgs A)
 {
     __shared__ int32_t sRefs[STACK * kBlock];
     __shared__ float sKeys[STACK * kBlock];
-    __shared__ float sRed[kBlock * 3];
     LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
     LaneCounters lc;
     const int lane = threadIdx.x & 63;
-    volatile float* red = sRed + (threadIdx.x & ~63) * 3;
+    // sample-sum staging: the traversal stack is empty between paths, so its first
+    // three rows (this wave's 64 columns) hold the wave's colours meanwhile
+    volatile float* red = sKeys + (threadIdx.x & ~63);
 
     const int slot = lane / A.lanesPerPixel, sub = lane % A.lanesPerPixel;
     const bool laneUsed = slot < A.pixelsPerUnit;
     const bool averaging = A.driver == RTX_DRIVER_MRAYS || A.driver == RTX_DRIVER_DOF || A.driver == RTX_DRIVER_MOTION_BLUR;
 
     for (;;) {
-        const uint32_t unit = fetchUnit(A.workCounter);
-        if (unit >= A.nUnits)
+        const uint32_t firstUnit = fetchUnits(A.workCounter, A.chunk);
+        if (firstUnit >= A.nUnits)
             break;
-        int x = 0, yTop = 0;
-        uint64_t outIndex = 0;
-        const bool pixelOk = laneUsed && pixelOfSequence(A, uint64_t(unit) * A.pixelsPerUnit + slot, x, yTop, outIndex);
-        const int y = A.H - 1 - yTop; // the reference's y runs bottom-up (src/screen.cpp:37-43)
-        const uint32_t pixelIndex = uint32_t(y) * uint32_t(A.W) + uint32_t(x);
-        // pixel corner, not centre (src/render.cpp:76-79)
-        const float ndcX = float(x) / float(A.W) * 2.0f - 1.0f, ndcY = float(y) / float(A.H) * 2.0f - 1.0f;
+        const uint32_t lastUnit = min(firstUnit + A.chunk, A.nUnits);
+        for (uint32_t unit = firstUnit; unit < lastUnit; unit++) {
         V3 accum = mk(0, 0, 0);
         for (int round = 0; round < A.rounds; round++) {
             const int sample = round * A.lanesPerPixel + sub;
-            const bool active = pixelOk && sample < A.samples;
             V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-            if (active) {
-                switch (A.driver) {
-                case RTX_DRIVER_MRAYS: {
-                    // src/render.cpp:170-176: x jitter then y jitter, draws 2*(pixel*spp+i)+{1,2}
-                    uint64_t rng = minstdAt((uint64_t(pixelIndex) * uint64_t(A.samples) + uint64_t(sample)) * 2ull);
-                    const float jx = minstdUniform(rng, 0.f, 1.f);
-                    const float jy = minstdUniform(rng, 0.f, 1.f);
-                    cameraRay(A.cam, float(float(x) + jx) / float(A.W) * 2.0f - 1.0f, float(float(y) + jy) / float(A.H) * 2.0f - 1.0f, o, d);
-                } break;
-                case RTX_DRIVER_DOF: {
-                    // src/render.cpp:113-117, src/dof.cpp:9-39
-                    V3 co, cd;
-                    cameraRay(A.cam, ndcX, ndcY, co, cd);
-                    const V3 focalPoint = co + A.focal * cd;
-                    uint64_t rng = minstdAt((uint64_t(pixelIndex) * uint64_t(A.samples) + uint64_t(sample)) * 3ull);
-                    const float sx = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
-                    const float sy = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
-                    const float sz = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
-                    o = co + mk(sx, sy, sz);
-                    d = normalize(focalPoint - o);
-                } break;
-                case RTX_DRIVER_MOTION_BLUR: {
-                    // src/render.cpp:203-247: the samples extrapolate from the current
-                    // pose by the pose change since the previous call
-                    uint64_t rng = minstdAt(uint64_t(pixelIndex) * uint64_t(A.samples) + uint64_t(sample));
-                    const float jitter = minstdUniform(rng, 0.f, 1.f);
-                    const float w = (jitter + float(sample)) / float(A.samples);
-                    const V3 lookAt = mk(A.cam.look_at) + w * (mk(A.cam.look_at) - mk(A.prev.look_at));
-                    const V3 euler = mk(A.cam.euler) + w * (mk(A.cam.euler) - mk(A.prev.euler));
-                    const float dist = A.cam.distance + w * (A.cam.distance - A.prev.distance);
-                    float qw;
-                    V3 qv;
-                    quatFromEuler(euler, qw, qv);
-                    const V3 dirCam = normalize(mk(-ndcX * A.cam.half_width, ndcY * A.cam.half_height, 1.0f));
-                    o = lookAt + rotate(qw, qv, mk(0, 0, -dist));
-                    d = rotate(qw, qv, dirCam);
-                } break;
-                default:
-                    cameraRay(A.cam, ndcX, ndcY, o, d);
-                    break;
+            bool active = false;
+            uint32_t key = 0;
+            {
+                // the pixel's coordinates are only needed to make the camera ray; they
+                // are derived again for the store below rather than kept in registers
+                // across the traversal loops
+                int x = 0, yTop = 0;
+                uint64_t outIndex = 0;
+                const bool pixelOk = laneUsed && pixelOfSequence(A, uint64_t(unit) * A.pixelsPerUnit + slot, x, yTop, outIndex);
+                const int y = A.H - 1 - yTop; // the reference's y runs bottom-up (src/screen.cpp:37-43)
+                const uint32_t pixelIndex = uint32_t(y) * uint32_t(A.W) + uint32_t(x);
+                // pixel corner, not centre (src/render.cpp:76-79)
+                const float ndcX = float(x) / float(A.W) * 2.0f - 1.0f, ndcY = float(y) / float(A.H) * 2.0f - 1.0f;
+                active = pixelOk && sample < A.samples;
+                if (FULL)
+                    key = sampleKey(A.seed, pixelIndex, uint32_t(sample));
+                if (active) {
+                    switch (A.driver) {
+                    case RTX_DRIVER_MRAYS: {
+                        // src/render.cpp:170-176: x jitter then y jitter, draws 2*(pixel*spp+i)+{1,2}
+                        uint64_t rng = driverRngState(A, x, y, pixelIndex, sample, 2);
+                        const float jx = minstdUniform(rng, 0.f, 1.f);
+                        const float jy = minstdUniform(rng, 0.f, 1.f);
+                        cameraRay(A.cam, float(float(x) + jx) / float(A.W) * 2.0f - 1.0f, float(float(y) + jy) / float(A.H) * 2.0f - 1.0f, o, d);
+                    } break;
+                    case RTX_DRIVER_DOF: {
+                        // src/render.cpp:113-117, src/dof.cpp:9-39
+                        V3 co, cd;
+                        cameraRay(A.cam, ndcX, ndcY, co, cd);
+                        const V3 focalPoint = co + A.focal * cd;
+                        uint64_t rng = driverRngState(A, x, y, pixelIndex, sample, 3);
+                        const float sx = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
+                        const float sy = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
+                        const float sz = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
+                        o = co + mk(sx, sy, sz);
+                        d = normalize(focalPoint - o);
+                    } break;
+                    case RTX_DRIVER_MOTION_BLUR:
+                        if (FULL) {
+                            // src/render.cpp:203-247: the samples extrapolate from the current
+                            // pose by the pose change since the previous call
+                            uint64_t rng = driverRngState(A, x, y, pixelIndex, sample, 1);
+                            const float jitter = minstdUniform(rng, 0.f, 1.f);
+                            const float w = (jitter + float(sample)) / float(A.samples);
+                            const V3 lookAt = mk(A.cam.look_at) + w * (mk(A.cam.look_at) - mk(A.prev.look_at));
+                            const V3 euler = mk(A.cam.euler) + w * (mk(A.cam.euler) - mk(A.prev.euler));
+                            const float dist = A.cam.distance + w * (A.cam.distance - A.prev.distance);
+                            float qw;
+                            V3 qv;
+                            quatFromEuler(euler, qw, qv);
+                            const V3 dirCam = normalize(mk(-ndcX * A.cam.half_width, ndcY * A.cam.half_height, 1.0f));
+                            o = lookAt + rotate(qw, qv, mk(0, 0, -dist));
+                            d = rotate(qw, qv, dirCam);
+                        }
+                        break;
+                    default:
+                        cameraRay(A.cam, ndcX, ndcY, o, d);
+                        break;
+                    }
                 }
             }
-            const uint32_t key = sampleKey(A.seed, pixelIndex, uint32_t(sample));
-            const V3 c = tracePath<STACK, COUNT, FULL>(A, st, o, d, active, key, lc);
+            const V3 c = FULL ? tracePath<STACK, COUNT, true>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
             } else {
                 // the reference adds the samples of a pixel one after another in
                 // sample order; reproduce that order exactly through LDS
-                red[lane * 3 + 0] = c.x;
-                red[lane * 3 + 1] = c.y;
-                red[lane * 3 + 2] = c.z;
+                red[0 * kBlock + lane] = c.x;
+                red[1 * kBlock + lane] = c.y;
+                red[2 * kBlock + lane] = c.z;
                 __builtin_amdgcn_wave_barrier();
-                if (pixelOk && sub == 0) {
+                if (laneUsed && sub == 0) {
                     const int n = min(A.lanesPerPixel, A.samples - round * A.lanesPerPixel);
                     for (int j = 0; j < n; j++) {
-                        const volatile float* q = red + (lane + j) * 3;
-                        accum = accum + mk(q[0], q[1], q[2]);
+                        const volatile float* q = red + (lane + j);
+                        accum = accum + mk(q[0 * kBlock], q[1 * kBlock], q[2 * kBlock]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (pixelOk && sub == 0) {
-            V3 px = accum;
-            if (A.driver == RTX_DRIVER_MRAYS) {
-                const float inv = 1.0f / (float(A.samples) * 1.0f);
-                px = accum * mk(inv, inv, inv);
-            } else if (A.driver == RTX_DRIVER_DOF) {
-                const float inv = 1.0f / float(A.samples);
-                px = accum * mk(inv, inv, inv);
-            } else if (A.driver == RTX_DRIVER_MOTION_BLUR) {
-                px = accum / float(A.samples);
+        if (laneUsed && sub == 0) {
+            // an opaque copy of the unit number keeps the compiler from carrying the
+            // coordinates computed before the traversal all the way down here
+            uint32_t unitAgain = unit;
+            asm volatile("" : "+s"(unitAgain));
+            int x = 0, yTop = 0;
+            uint64_t outIndex = 0;
+            if (pixelOfSequence(A, uint64_t(unitAgain) * A.pixelsPerUnit + slot, x, yTop, outIndex)) {
+                V3 px = accum;
+                if (A.driver == RTX_DRIVER_MRAYS) {
+                    const float inv = 1.0f / (float(A.samples) * 1.0f);
+                    px = accum * mk(inv, inv, inv);
+                } else if (A.driver == RTX_DRIVER_DOF) {
+                    const float inv = 1.0f / float(A.samples);
+                    px = accum * mk(inv, inv, inv);
+                } else if (A.driver == RTX_DRIVER_MOTION_BLUR) {
+                    px = accum / float(A.samples);
+                }
+                float* dst = A.out + outIndex * 3;
+                dst[0] = px.x;
+                dst[1] = px.y;
+                dst[2] = px.z;
             }
-            float* dst = A.out + outIndex * 3;
-            dst[0] = px.x;
-            dst[1] = px.y;
-            dst[2] = px.z;
+        }
         }
     }
     flushCounters<COUNT>(lc, A.stats);
@@ -600,7 +728,25 @@ struct DeviceCtx {
     unsigned long long* stats = nullptr;      // device, S_COUNT words
     int numCUs = 0;
     std::mutex launch;                        // one frame / batch at a time per GPU
+    // skip-ahead tables of the driver-level RNG, rebuilt when the frame shape changes
+    uint32_t* jump = nullptr;                 // device: kJumpCap words
+    int jumpW = -1, jumpH = -1, jumpS = -1, jumpD = -1;
 };
+constexpr int kJumpMaxDim = 32768, kJumpMaxSamples = 4096, kJumpCap = 2 * kJumpMaxDim + kJumpMaxSamples;
+
+uint64_t hostMulMod(uint64_t a, uint64_t b) { return (a * b) % 2147483647ull; }
+uint64_t hostPowMod(uint64_t base, uint64_t e)
+{
+    uint64_t r = 1;
+    base %= 2147483647ull;
+    while (e) {
+        if (e & 1)
+            r = hostMulMod(r, base);
+        base = hostMulMod(base, base);
+        e >>= 1;
+    }
+    return r;
+}
 thread_local DeviceCtx* g_ctx = nullptr;
 std::mutex g_ctxMutex;
 DeviceCtx g_ctxs[64];
@@ -649,20 +795,26 @@ int pickStack(int numLevels)
     return -1;
 }
 
-int gridFor(const DeviceCtx* c, const void* kernel)
+// Persistent grid: as many 4-wave blocks as a CU can ever hold (8 waves per
+// SIMD).  Blocks beyond what registers / LDS admit simply start when a resident
+// one retires and find the work counter exhausted; no block waits on another.
+int gridFor(const DeviceCtx* c, const void*)
 {
-    int perCU = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, 0) != hipSuccess || perCU < 1)
-        perCU = 2;
-    perCU = std::min(perCU, 8);
-    return c->numCUs * perCU;
+    return c->numCUs * 8;
+}
+// units claimed per atomic: enough that the counter is not the bottleneck, few
+// enough that every resident wave still gets ~16 fetches for load balance
+uint32_t chunkFor(const DeviceCtx* c, uint32_t nUnits)
+{
+    const uint32_t waves = uint32_t(c->numCUs) * 32u;
+    return std::max(1u, std::min(64u, nUnits / (waves * 16u)));
 }
 
 template <int STACK>
 int launchTrace(DeviceCtx* c, const TraceArgs& A, bool count)
 {
     const void* k = count ? (const void*)traceKernel<STACK, true> : (const void*)traceKernel<STACK, false>;
-    const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.nUnits + 3) / 4)));
+    const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.nUnits / A.chunk + 4) / 4)));
     if (count)
         hipLaunchKernelGGL((traceKernel<STACK, true>), dim3(grid), dim3(kBlock), 0, c->stream, A);
     else
@@ -676,7 +828,7 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, bool full)
 #define RTX_LAUNCH(CNT, FULLV)                                                                                     \
     {                                                                                                              \
         const void* k = (const void*)renderKernel<STACK, CNT, FULLV>;                                              \
-        const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.nUnits + 3) / 4)));                       \
+        const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.nUnits / A.chunk + 4) / 4)));                       \
         hipLaunchKernelGGL((renderKernel<STACK, CNT, FULLV>), dim3(grid), dim3(kBlock), 0, c->stream, A);          \
     }
     if (count && full)
@@ -761,6 +913,7 @@ int traceImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* d
     A.hits = dHits;
     A.n = n;
     A.nUnits = uint32_t((n + 63) / 64);
+    A.chunk = chunkFor(c, A.nUnits);
     A.workCounter = c->workCounter;
     A.stats = c->stats;
     HIP_TRY(hipMemsetAsync(c->workCounter, 0, sizeof(uint32_t), c->stream));
@@ -863,13 +1016,44 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         return RTX_ERR_LIMIT;
     }
     A.nUnits = uint32_t(units);
+    A.chunk = chunkFor(c, A.nUnits);
     A.workCounter = c->workCounter;
     A.stats = c->stats;
 
     // the full kernel carries the reflection / transparency / area-light /
     // texture / environment machinery; the lean one is enough otherwise
-    const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || driver == RTX_DRIVER_TRANSPARENCY;
+    const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || driver == RTX_DRIVER_TRANSPARENCY
+        || driver == RTX_DRIVER_MOTION_BLUR; // per-sample cameras need device trigonometry
 
+    // skip-ahead tables for the drivers that draw from the sequential engine
+    A.jumpX = c->jump;
+    A.jumpY = c->jump + kJumpMaxDim;
+    A.jumpS = c->jump + 2 * kJumpMaxDim;
+    A.jumpSamples = 0;
+    if (sampled) {
+        const int d = driver == RTX_DRIVER_MRAYS ? 2 : driver == RTX_DRIVER_DOF ? 3 : 1;
+        const int ns = std::min(A.samples, kJumpMaxSamples);
+        A.jumpSamples = ns;
+        if (c->jumpW != A.W || c->jumpH != A.H || c->jumpS != A.samples || c->jumpD != d) {
+            std::vector<uint32_t> t(size_t(A.W) + size_t(A.H) + size_t(ns));
+            const uint64_t perPixel = uint64_t(d) * uint64_t(A.samples);
+            const uint64_t g = hostPowMod(16807, perPixel), gRow = hostPowMod(g, uint64_t(A.W)), gS = hostPowMod(16807, uint64_t(d));
+            uint64_t v = 1;
+            for (int x = 0; x < A.W; x++, v = hostMulMod(v, g))
+                t[size_t(x)] = uint32_t(v);
+            v = 1;
+            for (int y = 0; y < A.H; y++, v = hostMulMod(v, gRow))
+                t[size_t(A.W) + size_t(y)] = uint32_t(v);
+            v = 1;
+            for (int i = 0; i < ns; i++, v = hostMulMod(v, gS))
+                t[size_t(A.W) + size_t(A.H) + size_t(i)] = uint32_t(v);
+            HIP_TRY(hipMemcpyAsync(c->jump, t.data(), size_t(A.W) * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->jump + kJumpMaxDim, t.data() + A.W, size_t(A.H) * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->jump + 2 * kJumpMaxDim, t.data() + A.W + A.H, size_t(ns) * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream)); // t goes out of scope
+            c->jumpW = A.W, c->jumpH = A.H, c->jumpS = A.samples, c->jumpD = d;
+        }
+    }
     HIP_TRY(hipMemsetAsync(c->workCounter, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * S_COUNT, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -918,6 +1102,7 @@ int rtx_init(int device)
         HIP_TRY(hipEventCreate(&c->ev1));
         HIP_TRY(hipMalloc((void**)&c->workCounter, 256));
         HIP_TRY(hipMalloc((void**)&c->stats, 256));
+        HIP_TRY(hipMalloc((void**)&c->jump, kJumpCap * sizeof(uint32_t)));
         c->device = device;
     }
     g_ctx = c;

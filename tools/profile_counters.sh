@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box: kernel trace + PMC counter passes over a short bench run.
+# Each counter pass is its own rocprofv3 run (the counter blocks have few slots).
+# Usage: tools/profile_counters.sh <outdir> [bench args...]
+set -u
+OUT=$1; shift
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1 || exit 1
+pass() {
+  name=$1; shift
+  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$OUT/$name.log"; exit 1; }
+}
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
+pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM
+pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
+pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+echo done
