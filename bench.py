@@ -90,11 +90,15 @@ def main():
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--obj-npz", default=None, help="scene .npz (raytracer_amd.scene.SceneData.save) to use instead of the stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-GPU render of it")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from raytracer_amd import abi, engine
+    from raytracer_amd.distributed import gather_tiles
     from raytracer_amd.scene import SceneData, dragon_scene, make_camera, make_params
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,10 +110,15 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     hip = engine.hip_lib()
     scene = SceneData.load(args.obj_npz) if args.obj_npz else dragon_scene()
@@ -135,7 +144,6 @@ def main():
         per = hip.rtx_tiles_per_rank(C.byref(rp))
         tiles = torch.zeros((per, args.tile, args.tile, 3), dtype=torch.float32, device=dev)
         gathered = torch.zeros((world,) + tuple(tiles.shape), dtype=torch.float32, device=dev) if rank == 0 else None
-        gather_list = list(gathered.unbind(0)) if rank == 0 else None
 
     def step(stats=None):
         sp = C.byref(stats) if stats is not None else None
@@ -143,7 +151,9 @@ def main():
             rc = hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(frame.data_ptr()), sp)
         else:
             rc = hip.rtx_render_tiles_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(tiles.data_ptr()), sp)
-            dist.gather(tiles, gather_list, dst=0)
+            if args.backend != "nccl":
+                torch.cuda.current_stream().synchronize()   # host-staged rehearsal path
+            gather_tiles(tiles, dst=0, out=gathered)
             if rank == 0 and rc == 0:
                 rc = hip.rtx_detile_device(C.c_void_p(gathered.data_ptr()), C.byref(rp), C.c_void_p(frame.data_ptr()))
         if rc != 0:
@@ -155,7 +165,8 @@ def main():
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce, st.shaded_hits], dtype=torch.float64, device=dev)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the small reductions live
+    counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce, st.shaded_hits], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(counts)
     rays_frame = float(counts[:3].sum())
@@ -175,11 +186,18 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps     # HIP events on the launch stream, per frame
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax[0])
 
+    if rank == 0 and args.check and world > 1:
+        ref = torch.zeros_like(frame)
+        one = make_params(args.width, args.height, driver=abi.DRIVER_MRAYS, samples=args.spp, tile_size=args.tile)
+        rc = hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(one), C.c_void_p(ref.data_ptr()), None)
+        torch.cuda.synchronize()
+        assert rc == 0 and torch.equal(ref, frame), "assembled multi-rank frame differs from the single-GPU frame"
+        print("check ok: assembled frame equals the single-GPU frame", file=sys.stderr)
     if rank == 0:
         value = rays_frame * args.steps / elapsed / 1e6
         out = {

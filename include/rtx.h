@@ -263,6 +263,16 @@ int rtx_render_tiles_device(const rtx_scene* scene, const rtx_camera* camera, co
  * rtx_tiles_per_rank*tile_size^2*3 floats each, rank-major) into a
  * Screen-layout frame.  Both pointers are device pointers. */
 int rtx_detile_device(const float* d_all_tiles, const rtx_render_params* params, float* d_out_rgb);
+/* Batch form of getFinalColor (src/render.h:29, src/render.cpp:16-66): the colour
+ * carried by each of n caller-supplied rays.  Of params only ray_depth (<0 = the
+ * reference's default 0), shadow_samples, glossy_rays and seed are read; ray i
+ * draws its light / glossy samples from the stream keyed (seed, i, 0).  rays and
+ * out_rgb (n x 3 floats) are host buffers; the _device form takes device pointers. */
+int rtx_shade(const rtx_scene* scene, const rtx_ray* rays, size_t n, const rtx_features* features,
+              const rtx_render_params* params, float* out_rgb, rtx_stats* stats);
+int rtx_shade_device(const rtx_scene* scene, const rtx_ray* d_rays, size_t n, const rtx_features* features,
+                     const rtx_render_params* params, float* d_out_rgb, rtx_stats* stats);
+
 /* Number of tiles each rank's compact buffer holds (the maximum over ranks). */
 int rtx_tiles_per_rank(const rtx_render_params* params);
 

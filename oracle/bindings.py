@@ -208,6 +208,12 @@ class OracleEngine(_Engine):
         self.fn("intersect")(vp(self.h), _ptr(rays), C.c_int64(len(rays)), C.byref(features), _ptr(hits), _ptr(self.counters), int(threads))
         return hits
 
+    def final_color(self, rays, features, params, threads=0):
+        rays = np.ascontiguousarray(rays, abi.RAY_DTYPE)
+        out = np.zeros((len(rays), 3), np.float32)
+        self.fn("shade")(vp(self.h), _ptr(rays), C.c_int64(len(rays)), C.byref(features), C.byref(params), _ptr(out), _ptr(self.counters), int(threads))
+        return out
+
     def render(self, cam, features, params, threads=0, **_):
         out = np.zeros((params.height, params.width, 3), np.float32)
         rc = self.fn("render")(vp(self.h), C.byref(cam), C.byref(features), C.byref(params), _ptr(out), _ptr(self.counters), int(threads))
@@ -291,6 +297,12 @@ class RefEngine(_Engine):
         hits = np.zeros(len(rays), abi.HIT_DTYPE)
         self.fn("intersect")(vp(self.b), vp(self.h), _ptr(rays), C.c_int64(len(rays)), C.byref(features), _ptr(hits))
         return hits
+
+    def final_color(self, rays, features, params, threads=0):
+        rays = np.ascontiguousarray(rays, abi.RAY_DTYPE)
+        out = np.zeros((len(rays), 3), np.float32)
+        self.fn("shade")(vp(self.h), vp(self.b), _ptr(rays), C.c_int64(len(rays)), C.byref(features), C.byref(params), _ptr(out))
+        return out
 
     def render(self, cam, features, params, threads=0, mode=0):
         """mode 0: the reference's own renderRayTracing* driver; mode 1: harness pixel

@@ -461,6 +461,25 @@ int ref_render(void* p, void* b, const rtx_camera* cam, const rtx_features* f, c
     return 0;
 }
 
+// getFinalColor for a batch of rays (sequential: the RNG shim's key is thread-local state)
+void ref_shade(void* p, void* b, const rtx_ray* rays, int64_t n, const rtx_features* f, const rtx_render_params* rp, float* out)
+{
+    auto* s = static_cast<RefScene*>(p);
+    const auto* bvh = static_cast<BvhInterface*>(b);
+    const Features feat = toFeatures(f);
+    sampleSize = rp->shadow_samples > 0 ? rp->shadow_samples : 50;
+    numberOfRays = rp->glossy_rays > 0 ? rp->glossy_rays : 5;
+    const int depth = rp->ray_depth >= 0 ? rp->ray_depth : 0;
+    rtx_shim_seed = rp->seed;
+    for (int64_t i = 0; i < n; i++) {
+        rtx_shim_pixel = uint32_t(i);
+        rtx_shim_sample = 0;
+        rtx_shim_counter = 0;
+        Ray r { v3(rays[i].origin), v3(rays[i].direction), rays[i].t };
+        put3(out + 3 * i, getFinalColor(s->scene, *bvh, r, feat, depth));
+    }
+}
+
 // ------------------------------------------------- per-function known answers
 int ref_kat_slab(const float* lo, const float* hi, rtx_ray* ray)
 {

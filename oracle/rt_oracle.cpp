@@ -1206,6 +1206,41 @@ int orc_render(void* p, const rtx_camera* cam, const rtx_features* f, const rtx_
     return 0;
 }
 
+// getFinalColor for a batch of rays; ray i draws from the stream keyed (seed, i, 0)
+void orc_shade(void* p, const rtx_ray* rays, int64_t n, const rtx_features* f, const rtx_render_params* rp, float* out, uint64_t* counters, int threads)
+{
+    const Scene& s = *static_cast<Scene*>(p);
+    const Feat feat = toFeat(f);
+    const int depth = rp->ray_depth >= 0 ? rp->ray_depth : 0;
+    Counters total;
+    if (threads <= 0)
+        threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+    {
+        Ctx cx { s, feat, rp->shadow_samples > 0 ? rp->shadow_samples : 50, rp->glossy_rays > 0 ? rp->glossy_rays : 5, PixelRng {}, Counters {} };
+        cx.rng.seed = rp->seed;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t i = 0; i < n; i++) {
+            Ray r;
+            r.o = mk(rays[i].origin);
+            r.d = mk(rays[i].direction);
+            r.t = rays[i].t;
+            cx.rng.start(uint32_t(i), 0);
+            put(out + 3 * i, finalColor(cx, r, depth, kPrimary));
+        }
+#pragma omp critical
+        total.add(cx.c);
+    }
+    if (counters) {
+        counters[0] = total.raysPrimary;
+        counters[1] = total.raysShadow;
+        counters[2] = total.raysBounce;
+        counters[3] = total.boxTests;
+        counters[4] = total.triTests;
+        counters[5] = total.shaded;
+    }
+}
+
 // ------------------------------------------------- per-function known answers
 int orc_kat_slab(const float* lo, const float* hi, rtx_ray* ray)
 {

@@ -213,7 +213,7 @@ enum Phase { PH_NEXT_LIGHT, PH_AFTER_LIGHTS, PH_NEXT_CHILD, PH_RETURN };
 // One camera sample from its first ray to its colour.  Every lane of the wave
 // calls this together; lanes without a sample pass active = false.
 template <int STACK, bool COUNT, bool FULL>
-RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD, bool active, uint32_t rngKey, LaneCounters& lc)
+RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD, bool active, uint32_t rngKey, LaneCounters& lc, float firstLimit = kFltMax)
 {
     const DScene& sc = A.sc;
     const rtx_features& f = A.f;
@@ -247,8 +247,10 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     bool shadowBehind = false;
 
     bool shadedPending = false; // counted at the loop head, where the wave is converged
+    bool firstQuery = true;
     while (__any(state != PS_DONE)) {
-        float t = kFltMax;
+        float t = firstQuery ? firstLimit : kFltMax;
+        firstQuery = false;
         Hit hit;
         bool any = false;
         lc.countShaded(shadedPending);
@@ -684,6 +686,50 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
     flushCounters<COUNT>(lc, A.stats);
 }
 
+// Batch form of getFinalColor (src/render.cpp:16-66): lane = caller-supplied ray.
+struct ShadeArgs {
+    RenderArgs R;          // scene, features, depth, sampling knobs, counters (frame fields unused)
+    const rtx_ray* rays;
+    float* out;            // n x RGB
+    uint64_t n;
+};
+
+template <int STACK, bool COUNT>
+__global__ void __launch_bounds__(kBlock, RTX_FULL_WAVES) shadeKernel(ShadeArgs S)
+{
+    __shared__ int32_t sRefs[STACK * kBlock];
+    __shared__ float sKeys[STACK * kBlock];
+    LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
+    LaneCounters lc;
+    const RenderArgs& A = S.R;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        const uint32_t first = fetchUnits(A.workCounter, A.chunk);
+        if (first >= A.nUnits)
+            break;
+        const uint32_t last = min(first + A.chunk, A.nUnits);
+        for (uint32_t unit = first; unit < last; unit++) {
+            const uint64_t i = uint64_t(unit) * 64 + lane;
+            const bool active = i < S.n;
+            V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+            float limit = kFltMax;
+            if (active) {
+                const rtx_ray r = S.rays[i];
+                o = mk(r.origin);
+                d = mk(r.direction);
+                limit = r.t;
+            }
+            const V3 c = tracePath<STACK, COUNT, true>(A, st, o, d, active, sampleKey(A.seed, uint32_t(i), 0u), lc, limit);
+            if (active) {
+                S.out[i * 3 + 0] = c.x;
+                S.out[i * 3 + 1] = c.y;
+                S.out[i * 3 + 2] = c.z;
+            }
+        }
+    }
+    flushCounters<COUNT>(lc, A.stats);
+}
+
 // scatter gathered compact tile buffers into a Screen-layout frame
 __global__ void detileKernel(const float* tiles, float* out, int W, int H, int ts, int tilesX, int tilesY, int world, int tilesPerRank)
 {
@@ -807,7 +853,10 @@ int gridFor(const DeviceCtx* c, const void*)
 uint32_t chunkFor(const DeviceCtx* c, uint32_t nUnits)
 {
     const uint32_t waves = uint32_t(c->numCUs) * 32u;
-    return std::max(1u, std::min(64u, nUnits / (waves * 16u)));
+    uint32_t chunk = nUnits / (waves * 16u);
+    if (chunk < 4u)
+        chunk = std::min(4u, std::max(1u, nUnits / waves)); // small launches: still at most nUnits/4 atomics
+    return std::min(64u, chunk);
 }
 
 template <int STACK>
@@ -1064,6 +1113,68 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         case 24: launchRender<24>(c, A, count, full); break;
         case 32: launchRender<32>(c, A, count, full); break;
         default: launchRender<64>(c, A, count, full); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    return fetchStats(c, stats, t0);
+}
+
+template <int STACK>
+void launchShade(DeviceCtx* c, const ShadeArgs& S, bool count)
+{
+    const int grid = std::max(1, std::min<int>(gridFor(c, nullptr), int((S.R.nUnits / S.R.chunk + 4) / 4)));
+    if (count)
+        hipLaunchKernelGGL((shadeKernel<STACK, true>), dim3(grid), dim3(kBlock), 0, c->stream, S);
+    else
+        hipLaunchKernelGGL((shadeKernel<STACK, false>), dim3(grid), dim3(kBlock), 0, c->stream, S);
+}
+
+int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_features* f, const rtx_render_params* p, float* dOut, rtx_stats* stats, double t0)
+{
+    DeviceCtx* c = g_ctx;
+    std::lock_guard<std::mutex> launchLock(c->launch);
+    if (n > (size_t(1) << 32) - 64) {
+        setErr("rtx_shade: %zu rays exceed the 2^32 limit (the ray index keys the sampler)", n);
+        return RTX_ERR_LIMIT;
+    }
+    const int stack = pickStack(scene->numLevels);
+    if (stack < 0) {
+        setErr("BVH has %d levels; the device traversal stack holds 64", scene->numLevels);
+        return RTX_ERR_LIMIT;
+    }
+    ShadeArgs S;
+    memset(&S, 0, sizeof(S));
+    RenderArgs& A = S.R;
+    A.sc = scene->d;
+    A.f = *f;
+    A.driver = RTX_DRIVER_PLAIN;
+    A.depth = p->ray_depth >= 0 ? p->ray_depth : 0; // getFinalColor's default rayDepth (src/render.h:29)
+    if (A.depth > kMaxDepth) {
+        setErr("ray_depth %d exceeds the limit of %d", A.depth, kMaxDepth);
+        return RTX_ERR_LIMIT;
+    }
+    A.samples = 1;
+    A.shadowSamples = p->shadow_samples > 0 ? p->shadow_samples : 50;
+    A.glossyRays = p->glossy_rays > 0 ? p->glossy_rays : 5;
+    A.seed = p->seed;
+    A.nUnits = uint32_t((n + 63) / 64);
+    A.chunk = chunkFor(c, A.nUnits);
+    A.workCounter = c->workCounter;
+    A.stats = c->stats;
+    S.rays = dRays;
+    S.out = dOut;
+    S.n = n;
+    HIP_TRY(hipMemsetAsync(c->workCounter, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * S_COUNT, c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (n) {
+        const bool count = wantCounters();
+        switch (stack) {
+        case 16: launchShade<16>(c, S, count); break;
+        case 24: launchShade<24>(c, S, count); break;
+        case 32: launchShade<32>(c, S, count); break;
+        default: launchShade<64>(c, S, count); break;
         }
         HIP_TRY(hipGetLastError());
     }
@@ -1352,6 +1463,54 @@ int rtx_render(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         setErr("rtx_render: framebuffer download failed");
         rc = RTX_ERR_DEVICE;
     }
+    (void)hipFree(dOut);
+    if (stats)
+        stats->total_ms = nowMs() - t0;
+    return rc;
+}
+
+int rtx_shade_device(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_features* f, const rtx_render_params* p, float* dOut, rtx_stats* stats)
+{
+    const double t0 = nowMs();
+    if (int rc = checkCtx(scene))
+        return rc;
+    if (!scene || !f || !p || (n && (!dRays || !dOut))) {
+        setErr("rtx_shade_device: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    return shadeImpl(scene, dRays, n, f, p, dOut, stats, t0);
+}
+
+int rtx_shade(const rtx_scene* scene, const rtx_ray* rays, size_t n, const rtx_features* f, const rtx_render_params* p, float* out, rtx_stats* stats)
+{
+    const double t0 = nowMs();
+    if (int rc = checkCtx(scene))
+        return rc;
+    if (!scene || !f || !p || (n && (!rays || !out))) {
+        setErr("rtx_shade: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    if (n == 0)
+        return shadeImpl(scene, nullptr, 0, f, p, nullptr, stats, t0);
+    rtx_ray* dRays = nullptr;
+    float* dOut = nullptr;
+    HIP_TRY(hipMalloc((void**)&dRays, n * sizeof(rtx_ray)));
+    if (hipMalloc((void**)&dOut, n * 3 * sizeof(float)) != hipSuccess) {
+        (void)hipFree(dRays);
+        setErr("rtx_shade: out of device memory for %zu colours", n);
+        return RTX_ERR_DEVICE;
+    }
+    int rc = RTX_OK;
+    if (hipMemcpyAsync(dRays, rays, n * sizeof(rtx_ray), hipMemcpyHostToDevice, g_ctx->stream) != hipSuccess) {
+        setErr("rtx_shade: ray upload failed");
+        rc = RTX_ERR_DEVICE;
+    }
+    rc = rc ? rc : shadeImpl(scene, dRays, n, f, p, dOut, stats, t0);
+    if (!rc && (hipStreamSynchronize(g_ctx->stream) != hipSuccess || hipMemcpy(out, dOut, n * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
+        setErr("rtx_shade: colour download failed");
+        rc = RTX_ERR_DEVICE;
+    }
+    (void)hipFree(dRays);
     (void)hipFree(dOut);
     if (stats)
         stats->total_ms = nowMs() - t0;

@@ -48,16 +48,27 @@ def assemble_tiles(all_tiles, width, height, tile_size, world):
     return frame
 
 
-def gather_tiles(local_tiles, dst=0):
+def gather_tiles(local_tiles, dst=0, out=None):
     """torch.distributed gather of every rank's compact tile buffer to `dst`
-    (RCCL over xGMI for GPU tensors, gloo for CPU tensors).  Returns the
-    rank-major stack on dst and None elsewhere."""
+    (RCCL over xGMI for GPU tensors under the nccl backend, gloo for CPU
+    tensors).  `out` is an optional preallocated (world, *local.shape) tensor on
+    dst.  Returns the rank-major stack on dst and None elsewhere.  With a
+    CPU-only backend and GPU tensors the tiles are staged through the host."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
+    staged = local_tiles
+    if local_tiles.is_cuda and dist.get_backend() == "gloo":
+        staged = local_tiles.cpu()
     if rank == dst:
-        out = torch.empty((world,) + tuple(local_tiles.shape), dtype=local_tiles.dtype, device=local_tiles.device)
-        dist.gather(local_tiles, list(out.unbind(0)), dst=dst)
-        return out
-    dist.gather(local_tiles, None, dst=dst)
+        if out is None or out.device != staged.device:
+            buf = torch.empty((world,) + tuple(staged.shape), dtype=staged.dtype, device=staged.device)
+        else:
+            buf = out
+        dist.gather(staged, list(buf.unbind(0)), dst=dst)
+        if out is not None and buf is not out:
+            out.copy_(buf)
+            return out
+        return buf
+    dist.gather(staged, None, dst=dst)
     return None

@@ -41,6 +41,8 @@ def hip_lib():
         lib.rtx_scene_retain.argtypes = [vp]
         lib.rtx_trace.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(abi.Features), C.POINTER(abi.Stats)]
         lib.rtx_trace_device.argtypes = lib.rtx_trace.argtypes
+        lib.rtx_shade.argtypes = [vp, vp, C.c_size_t, C.POINTER(abi.Features), C.POINTER(abi.RenderParams), vp, C.POINTER(abi.Stats)]
+        lib.rtx_shade_device.argtypes = lib.rtx_shade.argtypes
         for name in ("rtx_render", "rtx_render_device", "rtx_render_tiles_device"):
             getattr(lib, name).argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.Features), C.POINTER(abi.RenderParams), vp, C.POINTER(abi.Stats)]
         lib.rtx_detile_device.argtypes = [vp, C.POINTER(abi.RenderParams), vp]
@@ -223,6 +225,14 @@ class GpuEngine:
         out, hit = np.zeros(20, np.float32), C.c_int()
         _check(host_lib().rtxh_intersect_one(vp(self.b), _ptr(r), C.byref(features), _ptr(out), C.byref(hit)), "intersect_one")
         return bool(hit.value), np.float32(r["t"][0]), out
+
+    def final_color(self, rays, features, ray_depth=0, one_by_one=False):
+        """getFinalColor (src/render.h:29) for a batch of rays."""
+        rays = np.ascontiguousarray(rays, abi.RAY_DTYPE)
+        out = np.zeros((len(rays), 3), np.float32)
+        _check(host_lib().rtxh_final_color(vp(self.b), _ptr(rays), C.c_int64(len(rays)), C.byref(features), int(ray_depth), _ptr(out),
+                                           int(one_by_one), C.byref(self.stats)), "final_color")
+        return out
 
     def render(self, cam, features, params, **_):
         out = np.zeros((params.height, params.width, 3), np.float32)

@@ -257,6 +257,28 @@ int rtxh_intersect_one(const void* b, rtx_ray* ray, const rtx_features* f, float
     });
 }
 
+// getFinalColor for n rays (one batch), or ray by ray through the single-ray
+// function when oneByOne is set
+int rtxh_final_color(const void* b, const rtx_ray* rays, int64_t n, const rtx_features* f, int rayDepth, float* out, int oneByOne, rtx_stats* stats)
+{
+    return guarded([&] {
+        const auto* bvh = static_cast<const BvhInterface*>(b);
+        static_assert(sizeof(vec3) == 12, "vec3 must be three packed floats");
+        if (!oneByOne) {
+            getFinalColorBatch(*bvh, rays, size_t(n), toFeatures(f), rayDepth, reinterpret_cast<vec3*>(out), stats);
+            return;
+        }
+        for (int64_t i = 0; i < n; i++) {
+            Ray r;
+            r.origin = v3(rays[i].origin);
+            r.direction = v3(rays[i].direction);
+            r.t = rays[i].t;
+            const vec3 c = getFinalColor(*bvh->scene(), *bvh, r, toFeatures(f), rayDepth);
+            out[3 * i] = c.x, out[3 * i + 1] = c.y, out[3 * i + 2] = c.z;
+        }
+    });
+}
+
 // any driver, explicit parameters (renderFrame)
 int rtxh_render(const void* b, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* rp, float* out, rtx_stats* stats)
 {

@@ -280,6 +280,29 @@ struct BlurState {
 BlurState g_blur;
 } // namespace
 
+void getFinalColorBatch(const BvhInterface& bvh, const rtx_ray* rays, size_t n, const Features& features, int rayDepth, vec3* out, rtx_stats* stats)
+{
+    ensureDevice();
+    rtx_render_params p = baseParams(RTX_DRIVER_PLAIN);
+    p.ray_depth = rayDepth;
+    p.shadow_samples = sampleSize;
+    p.glossy_rays = numberOfRays;
+    const rtx_features f = toDeviceFeatures(features);
+    if (rtx_shade(bvh.deviceScene(), rays, n, &f, &p, n ? &out[0].x : nullptr, stats) != RTX_OK)
+        fail("rtx_shade");
+}
+
+vec3 getFinalColor(const Scene&, const BvhInterface& bvh, Ray ray, const Features& features, int rayDepth)
+{
+    rtx_ray r;
+    std::memcpy(r.origin, &ray.origin, 12);
+    std::memcpy(r.direction, &ray.direction, 12);
+    r.t = ray.t;
+    vec3 out;
+    getFinalColorBatch(bvh, &r, 1, features, rayDepth, &out);
+    return out;
+}
+
 void renderRayTracing(const Scene&, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features)
 {
     renderFrame(bvh, camera, screen, features, baseParams(RTX_DRIVER_PLAIN));

@@ -123,6 +123,12 @@ void renderRayTracingMotionBlur(const Scene& scene, const Trackball& camera, con
 // Forget the remembered motion-blur camera (the reference never does).
 void resetMotionBlur();
 
+// src/render.h:29: the colour carried by one ray.  One device launch per call;
+// getFinalColorBatch shades n rays at once (ray i samples lights / glossy
+// directions from the stream keyed (samplingSeed, i, 0)).
+vec3 getFinalColor(const Scene& scene, const BvhInterface& bvh, Ray ray, const Features& features, int rayDepth = 0);
+void getFinalColorBatch(const BvhInterface& bvh, const rtx_ray* rays, size_t n, const Features& features, int rayDepth, vec3* out, rtx_stats* stats = nullptr);
+
 // General form behind the five drivers: any driver with an explicit ray depth
 // (the reference's drivers hard-code 0 or 1), optional interleaved-tile
 // partition, statistics.

@@ -102,6 +102,20 @@ IMAGE_CASES = [
 
 CASES_BY_NAME = {c.name: c for c in IMAGE_CASES}
 
+# getFinalColor on caller-supplied rays: (name, scene, features, params, lights)
+SHADE_CASES = [
+    ("cornell_area_glossy_d2", "cornell", dict(BASE, soft_shadow=1, recursive=1, glossy_reflection=1),
+     dict(width=1, height=1, ray_depth=2, shadow_samples=4, glossy_rays=3), _AREA),
+    ("monkey_default_depth", "monkey", dict(BASE, recursive=1), dict(width=1, height=1), None),
+]
+
+
+def shade_rays(grid=40):
+    from oracle.bindings import primary_rays
+    rays = primary_rays(make_camera(), grid, grid)
+    rays["t"][::9] = 2.9        # a search limit in front of part of the scene
+    return rays
+
 
 def ray_batch(scene: SceneData, seed, n_random=1500, grid=48):
     """Primary rays through a grid of pixel corners plus random rays started inside

@@ -42,6 +42,11 @@ def golden_images():
 
 
 @pytest.fixture(scope="session")
+def golden_shade():
+    return _npz("shade.npz")
+
+
+@pytest.fixture(scope="session")
 def gpu_device():
     """Fails (never skips) when the HIP library or the GPU is missing: the GPU tests
     must not pass on a machine where the native path did not run."""

@@ -15,6 +15,7 @@ Outputs (all data, no reference source):
                         lists and node boxes in depth-first order
     rays.npz            per scene: a ray batch and the reference's HitInfo for it
     images.npz          per image case: the reference's frame (fp32 RGB)
+    shade.npz           getFinalColor on a batch of caller-supplied rays
     kat.npz             per-function known answers (slab, triangle, sphere,
                         barycentric, shading, reflection, textures, mip chain,
                         environment map, light sampling, glossy fan, RNG stream)
@@ -110,6 +111,21 @@ def make_images():
         ref.close()
         print("image", c.name, out[c.name].shape, float(np.nansum(out[c.name])))
     np.savez_compressed(os.path.join(OUT, "images.npz"), **out)
+
+
+def make_shade():
+    out = {"rays": cases.shade_rays()}
+    for name, scene_name, feat, params, lights in cases.SHADE_CASES:
+        scene = cases.load_scene(scene_name)
+        if lights is not None:
+            scene.lights = list(lights)
+        f = abi.features(**feat)
+        ref = RefEngine(scene, f)
+        from raytracer_amd.scene import make_params
+        out[name] = ref.final_color(out["rays"], f, make_params(**params))
+        ref.close()
+        print("shade", name, float(np.nansum(out[name])))
+    np.savez_compressed(os.path.join(OUT, "shade.npz"), **out)
 
 
 def make_kat():
@@ -248,6 +264,6 @@ def make_kat():
 if __name__ == "__main__":
     if not have_ref():
         sys.exit("oracle/_ref/libref.so is missing: run `make -C oracle ref` where /root/reference exists")
-    what = sys.argv[1:] or ["scenes", "bvh", "rays", "images", "kat"]
+    what = sys.argv[1:] or ["scenes", "bvh", "rays", "images", "shade", "kat"]
     for w in what:
         globals()["make_" + w]()

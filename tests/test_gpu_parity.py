@@ -104,6 +104,90 @@ def test_named_drivers_use_reference_defaults(gpu_device, golden_images):
         assert_images_close(got, golden_images[name], name + " (named driver)", max(RGB_TOL, case.tol))
 
 
+def test_get_final_color_matches_reference_and_oracle(gpu_device, golden_shade):
+    """getFinalColor (src/render.h:29) on caller-supplied rays, batched and ray by ray."""
+    rays = golden_shade["rays"]
+    for name, scene_name, feat, params, lights in cases.SHADE_CASES:
+        scene = cases.load_scene(scene_name)
+        if lights is not None:
+            scene.lights = list(lights)
+        f = abi.features(**feat)
+        rp = make_params(**params)
+        gpu = GpuEngine(scene, f)
+        from raytracer_amd.engine import host_lib
+        host_lib().rtxh_set_sampling(rp.shadow_samples, rp.glossy_rays, rp.seed)
+        got = gpu.final_color(rays, f, ray_depth=max(rp.ray_depth, 0))
+        stats = gpu.stats
+        rays_gpu = (stats.rays_primary, stats.rays_shadow, stats.rays_bounce)
+        if name == "monkey_default_depth":   # single-ray entry point: ray 0 is keyed (seed, 0, 0) either way
+            one = gpu.final_color(rays[:1], f, ray_depth=0, one_by_one=True)
+            assert np.array_equal(one[0], got[0], equal_nan=True)
+        host_lib().rtxh_set_sampling(50, 5, 1)
+        gpu.close()
+        orc = OracleEngine(scene, f)
+        want = orc.final_color(rays, f, rp)
+        assert rays_gpu == tuple(int(x) for x in orc.counters[:3]), name
+        orc.close()
+        assert_images_close(got, want, name + " vs oracle")
+        assert_images_close(got, golden_shade[name], name + " vs reference")
+
+
+def test_shadow_query_shortcuts_do_not_change_frames(gpu_device):
+    """The shortened shadow queries must give the reference's answer in the regimes
+    where they switch on and off: light closer than 0.2 to surfaces, coordinates
+    beyond 64 (scene scaled x100), light inside the scene's bounds, spheres."""
+    base = cases.load_scene("monkey")
+    f = abi.features(**cases.BASE)
+    for tag, scale, light in (("near light", 1.0, (0.05, 0.1, -0.55)), ("inside bounds", 1.0, (0.0, 0.0, 0.0)),
+                              ("scaled x100", 100.0, (-100.0, 100.0, -100.0)), ("scaled x40, near", 40.0, (2.0, 4.0, -24.0))):
+        scene = cases.load_scene("monkey")
+        scene.meshes[0].vertices[:, :3] = base.meshes[0].vertices[:, :3] * np.float32(scale)
+        scene.lights = [abi.point_light(light), abi.point_light((3 * scale, -1 * scale, -2 * scale), (0.3, 0.2, 0.1))]
+        cam = make_camera(distance=3.0 * scale)
+        rp = make_params(96, 96)
+        gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+        assert_images_close(gpu.render(cam, f, rp), orc.render(cam, f, rp), "lean path, " + tag, 1e-3 * max(1.0, 1.0))
+        ff = abi.features(**dict(cases.BASE, recursive=1))
+        assert_images_close(gpu.render(cam, ff, rp), orc.render(cam, ff, rp), "general path, " + tag)
+        gpu.close()
+        orc.close()
+
+
+def test_compact_tiles_and_detile_on_device(gpu_device):
+    """The multi-GPU data path on one GPU: every rank's compact tile buffer
+    (rtx_render_tiles_device), stacked as the gather leaves them, scattered by
+    rtx_detile_device, equals the whole-frame render."""
+    import ctypes as C
+    import torch
+    from raytracer_amd import engine
+    from raytracer_amd.distributed import assemble_tiles
+    hip = engine.hip_lib()
+    scene = cases.load_scene("teapot")
+    f = abi.features(**cases.BASE)
+    gpu = GpuEngine(scene, f)
+    w, h, ts = 200, 120, 16
+    cam = engine.device_camera(make_camera(), w, h)
+    dev = torch.device("cuda", 0)
+    whole = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    one = make_params(w, h, driver=abi.DRIVER_MRAYS, samples=4, tile_size=ts)
+    st = abi.Stats()
+    assert hip.rtx_render_device(gpu.device_scene(), C.byref(cam), C.byref(f), C.byref(one), C.c_void_p(whole.data_ptr()), C.byref(st)) == 0
+    for world in (2, 5, 8):
+        per = hip.rtx_tiles_per_rank(C.byref(make_params(w, h, tile_size=ts, tile_world=world)))
+        stack = torch.zeros((world, per, ts, ts, 3), dtype=torch.float32, device=dev)
+        for rank in range(world):
+            rp = make_params(w, h, driver=abi.DRIVER_MRAYS, samples=4, tile_size=ts, tile_rank=rank, tile_world=world)
+            assert hip.rtx_render_tiles_device(gpu.device_scene(), C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(stack[rank].data_ptr()), C.byref(st)) == 0
+        out = torch.zeros_like(whole)
+        rp = make_params(w, h, tile_size=ts, tile_world=world)
+        assert hip.rtx_detile_device(C.c_void_p(stack.data_ptr()), C.byref(rp), C.c_void_p(out.data_ptr())) == 0
+        assert hip.rtx_synchronize() == 0
+        assert torch.equal(out, whole), f"world {world}"
+        # and the CPU statement of the layout agrees with the device's
+        assert np.array_equal(assemble_tiles(stack.cpu().numpy(), w, h, ts, world), whole.cpu().numpy())
+    gpu.close()
+
+
 def test_bvh_interface_single_ray_hitinfo(gpu_device):
     """BvhInterface::intersect(Ray&, HitInfo&, Features): ray.t in/out, HitInfo filled."""
     scene = cases.load_scene("cornell")

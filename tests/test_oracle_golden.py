@@ -167,3 +167,21 @@ def test_frames_bit_exact(golden_images, case):
     ok = ~np.isnan(want)
     assert np.array_equal(bits(got)[ok], bits(want)[ok]), f"max |diff| {np.nanmax(np.abs(got - want))}"
     assert np.nansum(want) > 0
+
+
+def test_get_final_color_batches_bit_exact(golden_shade):
+    from raytracer_amd.scene import make_params
+    rays = golden_shade["rays"]
+    for name, scene_name, feat, params, lights in cases.SHADE_CASES:
+        scene = cases.load_scene(scene_name)
+        if lights is not None:
+            scene.lights = list(lights)
+        f = abi.features(**feat)
+        orc = OracleEngine(scene, f)
+        got = orc.final_color(rays, f, make_params(**params), threads=4)
+        orc.close()
+        want = golden_shade[name]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        assert np.array_equal(bits(got)[ok], bits(want)[ok]), name
+        assert np.nansum(want) > 0
