@@ -61,6 +61,16 @@ RTX_DEV uint64_t waveSum(uint32_t v)
     return s;
 }
 
+// The statistics words are kept in kStatSlots copies, each on its own 256-byte
+// line, and added up on the host: thousands of waves finishing together would
+// otherwise queue their atomics on one memory channel.
+constexpr int kStatSlots = 64, kStatStride = 32; // stride in 64-bit words
+
+RTX_DEV uint32_t waveIndex()
+{
+    return __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+}
+
 template <bool COUNT>
 RTX_DEV void flushCounters(const LaneCounters& c, unsigned long long* stats)
 {
@@ -70,26 +80,72 @@ RTX_DEV void flushCounters(const LaneCounters& c, unsigned long long* stats)
         tr = waveSum(c.tc.triTests);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&stats[S_PRIMARY], (unsigned long long)c.primary);
-        atomicAdd(&stats[S_SHADOW], (unsigned long long)c.shadow);
-        atomicAdd(&stats[S_BOUNCE], (unsigned long long)c.bounce);
-        atomicAdd(&stats[S_SHADED], (unsigned long long)c.shaded);
+        unsigned long long* slot = stats + size_t(waveIndex() % kStatSlots) * kStatStride;
+        atomicAdd(&slot[S_PRIMARY], (unsigned long long)c.primary);
+        atomicAdd(&slot[S_SHADOW], (unsigned long long)c.shadow);
+        atomicAdd(&slot[S_BOUNCE], (unsigned long long)c.bounce);
+        atomicAdd(&slot[S_SHADED], (unsigned long long)c.shaded);
         if (COUNT) {
-            atomicAdd(&stats[S_BOX], (unsigned long long)bx);
-            atomicAdd(&stats[S_TRI], (unsigned long long)tr);
+            atomicAdd(&slot[S_BOX], (unsigned long long)bx);
+            atomicAdd(&slot[S_TRI], (unsigned long long)tr);
         }
     }
 }
 
-// Work fetch, wave-uniform: one atomic claims `chunk` consecutive units.  A single
-// counter word serves only ~90 fetches per microsecond chip-wide, so a frame of
-// half a million 64-lane units must not pay one atomic each.
-RTX_DEV uint32_t fetchUnits(uint32_t* counter, uint32_t chunk)
+// ------------------------------------------------------------ work queue ----
+// The launch's 64-lane units are handed out in chunks of `chunk` consecutive
+// units.  One atomic counter serves only ~90 claims per microsecond chip-wide (the
+// atomics of all XCDs meet at one memory channel), far too few for half a million
+// units per frame, so the chunks are dealt round-robin onto kQueues ticket
+// counters, each on its own 256-byte line: counter c hands out chunks c,
+// c + kQueues, c + 2 kQueues, ...  A wave draws from its home counter and claims
+// the NEXT chunk before it starts on the current one, so the atomic's round trip
+// is hidden behind the work.  When a counter is spent the wave reads all counters
+// at once (lane i reads counter i) and moves to the next one that still has chunks.
+constexpr int kQueues = 64, kQueueStride = 64; // stride in 32-bit words
+
+struct WorkQueue {
+    uint32_t* tickets;
+    uint32_t nUnits, chunk, nChunks;
+};
+struct WorkCursor {
+    uint32_t queue;  // wave-uniform: the counter this wave draws from
+    uint32_t ticket; // lane 0: result of the claim in flight
+};
+RTX_DEV void claimTicket(const WorkQueue& q, WorkCursor& w)
 {
-    uint32_t u = 0;
+    uint32_t k = 0;
     if ((threadIdx.x & 63) == 0)
-        u = atomicAdd(counter, chunk);
-    return __builtin_amdgcn_readfirstlane(u);
+        k = atomicAdd(q.tickets + w.queue * kQueueStride, 1u);
+    w.ticket = k;
+}
+RTX_DEV void openCursor(const WorkQueue& q, WorkCursor& w)
+{
+    w.queue = waveIndex() % kQueues;
+    claimTicket(q, w);
+}
+// Units [first, last) of the next chunk; false once every chunk has been handed out.
+RTX_DEV bool nextChunk(const WorkQueue& q, WorkCursor& w, uint32_t& first, uint32_t& last)
+{
+    for (;;) {
+        const uint32_t k = __builtin_amdgcn_readfirstlane(w.ticket);
+        const uint64_t id = uint64_t(k) * kQueues + w.queue;
+        if (id < q.nChunks) {
+            claimTicket(q, w);
+            first = uint32_t(id) * q.chunk;
+            last = first + min(q.chunk, q.nUnits - first);
+            return true;
+        }
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t seen = __hip_atomic_load(q.tickets + lane * kQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t open = __ballot(uint64_t(seen) * kQueues + lane < q.nChunks);
+        if (!open)
+            return false;
+        const uint32_t c = w.queue;
+        const uint64_t ahead = ((open >> 1) >> c) | (open << (63 - c)); // bit j: counter (c + 1 + j) % 64
+        w.queue = (c + 1 + uint32_t(__builtin_ctzll(ahead))) & 63u;
+        claimTicket(q, w);
+    }
 }
 
 // ---------------------------------------------------------- trace kernel ----
@@ -99,8 +155,7 @@ struct TraceArgs {
     const rtx_ray* rays;
     rtx_hit* hits;
     uint64_t n;
-    uint32_t nUnits, chunk;
-    uint32_t* workCounter;
+    WorkQueue work;
     unsigned long long* stats;
 };
 
@@ -112,11 +167,10 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceArgs A)
     LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
     LaneCounters lc;
     const int lane = threadIdx.x & 63;
-    for (;;) {
-        const uint32_t first = fetchUnits(A.workCounter, A.chunk);
-        if (first >= A.nUnits)
-            break;
-        const uint32_t last = min(first + A.chunk, A.nUnits);
+    WorkCursor cursor;
+    openCursor(A.work, cursor);
+    uint32_t first, last;
+    while (nextChunk(A.work, cursor, first, last)) {
         for (uint32_t unit = first; unit < last; unit++) {
         const uint64_t i = uint64_t(unit) * 64 + lane;
         lc.countPrimary(i < A.n);
@@ -156,8 +210,7 @@ struct RenderArgs {
     // sequence x lanesPerPixel samples, repeated `rounds` times when a pixel has
     // more than 64 samples
     int32_t pixelsPerUnit, lanesPerPixel, rounds;
-    uint32_t nUnits, chunk;
-    uint32_t* workCounter;
+    WorkQueue work;
     unsigned long long* stats;
     // skip-ahead tables of the driver-level engine: its state before sample s of
     // pixel (x, y) is jumpX[x] * jumpY[y] * jumpS[s] mod 2^31-1
@@ -168,17 +221,18 @@ struct RenderArgs {
 // q-th pixel of this rank's tile sequence: tiles in rank order, 8x8 blocks
 // row-major inside a tile, Morton order inside a block.  Returns false for
 // padding outside the image.  yTop counts rows from the top (Screen rows).
-RTX_DEV bool pixelOfSequence(const RenderArgs& A, uint64_t q, int& x, int& yTop, uint64_t& outIndex)
+RTX_DEV bool pixelOfSequence(const RenderArgs& A, uint32_t q, int& x, int& yTop, uint32_t& outIndex)
 {
+    // q < 2^32: a padded frame has at most (32768 + 1023)^2 pixels
     const uint32_t ts = A.tileSize, tilePixels = ts * ts;
-    const uint32_t k = uint32_t(q / tilePixels), r = uint32_t(q % tilePixels);
+    const uint32_t k = q / tilePixels, r = q - k * tilePixels;
     if (k >= uint32_t(A.tilesMine))
         return false;
     const uint32_t tile = A.tileRank + k * A.tileWorld;
-    const uint32_t tx = tile % A.tilesX, ty = tile / A.tilesX;
+    const uint32_t ty = tile / uint32_t(A.tilesX), tx = tile - ty * uint32_t(A.tilesX);
     const uint32_t blocksPerRow = ts / 8;
     const uint32_t blk = r / 64, m = r % 64;
-    const uint32_t bx = blk % blocksPerRow, by = blk / blocksPerRow;
+    const uint32_t by = blk / blocksPerRow, bx = blk - by * blocksPerRow;
     // de-interleave the 6 Morton bits
     const uint32_t mx = (m & 1) | ((m >> 1) & 2) | ((m >> 2) & 4);
     const uint32_t my = ((m >> 1) & 1) | ((m >> 2) & 2) | ((m >> 3) & 4);
@@ -187,8 +241,20 @@ RTX_DEV bool pixelOfSequence(const RenderArgs& A, uint64_t q, int& x, int& yTop,
     yTop = int(ty * ts + ly);
     if (x >= A.W || yTop >= A.H)
         return false;
-    outIndex = A.compact ? (uint64_t(k) * tilePixels + uint64_t(ly) * ts + lx) : (uint64_t(yTop) * A.W + x);
+    outIndex = A.compact ? (k * tilePixels + ly * ts + lx) : (uint32_t(yTop) * uint32_t(A.W) + uint32_t(x));
     return true;
+}
+
+RTX_DEV float fromLane(float v, int lane) // lane: wave-uniform
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// The value the previous lane of the wave holds (lane 0 receives 0): DPP
+// wave_shr:1.  Must run with every lane of the wave enabled, since a disabled
+// source lane reads as 0.
+RTX_DEV float fromPreviousLane(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
 
 // state of the driver-level engine before the first draw of `sample` of pixel (x, y)
@@ -558,21 +624,19 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
     LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
     LaneCounters lc;
     const int lane = threadIdx.x & 63;
-    // sample-sum staging: the traversal stack is empty between paths, so its first
-    // three rows (this wave's 64 columns) hold the wave's colours meanwhile
-    volatile float* red = sKeys + (threadIdx.x & ~63);
-
     const int slot = lane / A.lanesPerPixel, sub = lane % A.lanesPerPixel;
     const bool laneUsed = slot < A.pixelsPerUnit;
     const bool averaging = A.driver == RTX_DRIVER_MRAYS || A.driver == RTX_DRIVER_DOF || A.driver == RTX_DRIVER_MOTION_BLUR;
+    // the lane that ends up holding its pixel's sum and stores it
+    const bool writer = laneUsed && sub == A.lanesPerPixel - 1;
 
-    for (;;) {
-        const uint32_t firstUnit = fetchUnits(A.workCounter, A.chunk);
-        if (firstUnit >= A.nUnits)
-            break;
-        const uint32_t lastUnit = min(firstUnit + A.chunk, A.nUnits);
+    WorkCursor cursor;
+    openCursor(A.work, cursor);
+    uint32_t firstUnit, lastUnit;
+    while (nextChunk(A.work, cursor, firstUnit, lastUnit)) {
         for (uint32_t unit = firstUnit; unit < lastUnit; unit++) {
         V3 accum = mk(0, 0, 0);
+        V3 carry = mk(0, 0, 0); // sum of the rounds so far (a pixel with more than 64 samples owns the wave)
         for (int round = 0; round < A.rounds; round++) {
             const int sample = round * A.lanesPerPixel + sub;
             V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
@@ -583,8 +647,8 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                 // are derived again for the store below rather than kept in registers
                 // across the traversal loops
                 int x = 0, yTop = 0;
-                uint64_t outIndex = 0;
-                const bool pixelOk = laneUsed && pixelOfSequence(A, uint64_t(unit) * A.pixelsPerUnit + slot, x, yTop, outIndex);
+                uint32_t outIndex = 0;
+                const bool pixelOk = laneUsed && pixelOfSequence(A, unit * uint32_t(A.pixelsPerUnit) + uint32_t(slot), x, yTop, outIndex);
                 const int y = A.H - 1 - yTop; // the reference's y runs bottom-up (src/screen.cpp:37-43)
                 const uint32_t pixelIndex = uint32_t(y) * uint32_t(A.W) + uint32_t(x);
                 // pixel corner, not centre (src/render.cpp:76-79)
@@ -641,30 +705,39 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
             if (!averaging) {
                 accum = c;
             } else {
-                // the reference adds the samples of a pixel one after another in
-                // sample order; reproduce that order exactly through LDS
-                red[0 * kBlock + lane] = c.x;
-                red[1 * kBlock + lane] = c.y;
-                red[2 * kBlock + lane] = c.z;
-                __builtin_amdgcn_wave_barrier();
-                if (laneUsed && sub == 0) {
-                    const int n = min(A.lanesPerPixel, A.samples - round * A.lanesPerPixel);
-                    for (int j = 0; j < n; j++) {
-                        const volatile float* q = red + (lane + j);
-                        accum = accum + mk(q[0 * kBlock], q[1 * kBlock], q[2 * kBlock]);
-                    }
+                // The reference adds the samples of a pixel one after another, in sample
+                // order, onto a zero (src/render.cpp:168-178).  The samples sit in
+                // consecutive lanes, so that chain is a running sum along the lanes:
+                // after step j the lane of sample j holds ((0 + c0) + c1) + ... + cj.
+                const int n = min(A.lanesPerPixel, A.samples - round * A.lanesPerPixel); // samples of this round
+                const bool head = sub == 0;
+                // (selects written per component: a select between two V3 objects is
+                // lowered to an indexed copy through scratch memory)
+                float rx = head ? carry.x + c.x : c.x, ry = head ? carry.y + c.y : c.y, rz = head ? carry.z + c.z : c.z;
+                for (int j = 1; j < n; j++) {
+                    const float nx = fromPreviousLane(rx) + c.x, ny = fromPreviousLane(ry) + c.y, nz = fromPreviousLane(rz) + c.z;
+                    rx = head ? rx : nx;
+                    ry = head ? ry : ny;
+                    rz = head ? rz : nz;
                 }
-                __builtin_amdgcn_wave_barrier();
+                const V3 run = mk(rx, ry, rz);
+                if (A.rounds > 1) {
+                    // one pixel per wave: its sum so far sits in lane n - 1
+                    carry = mk(fromLane(run.x, n - 1), fromLane(run.y, n - 1), fromLane(run.z, n - 1));
+                    accum = carry;
+                } else {
+                    accum = run;
+                }
             }
         }
-        if (laneUsed && sub == 0) {
+        if (writer) {
             // an opaque copy of the unit number keeps the compiler from carrying the
             // coordinates computed before the traversal all the way down here
             uint32_t unitAgain = unit;
             asm volatile("" : "+s"(unitAgain));
             int x = 0, yTop = 0;
-            uint64_t outIndex = 0;
-            if (pixelOfSequence(A, uint64_t(unitAgain) * A.pixelsPerUnit + slot, x, yTop, outIndex)) {
+            uint32_t outIndex = 0;
+            if (pixelOfSequence(A, unitAgain * uint32_t(A.pixelsPerUnit) + uint32_t(slot), x, yTop, outIndex)) {
                 V3 px = accum;
                 if (A.driver == RTX_DRIVER_MRAYS) {
                     const float inv = 1.0f / (float(A.samples) * 1.0f);
@@ -675,7 +748,7 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                 } else if (A.driver == RTX_DRIVER_MOTION_BLUR) {
                     px = accum / float(A.samples);
                 }
-                float* dst = A.out + outIndex * 3;
+                float* dst = A.out + size_t(outIndex) * 3;
                 dst[0] = px.x;
                 dst[1] = px.y;
                 dst[2] = px.z;
@@ -703,11 +776,10 @@ __global__ void __launch_bounds__(kBlock, RTX_FULL_WAVES) shadeKernel(ShadeArgs 
     LaneCounters lc;
     const RenderArgs& A = S.R;
     const int lane = threadIdx.x & 63;
-    for (;;) {
-        const uint32_t first = fetchUnits(A.workCounter, A.chunk);
-        if (first >= A.nUnits)
-            break;
-        const uint32_t last = min(first + A.chunk, A.nUnits);
+    WorkCursor cursor;
+    openCursor(A.work, cursor);
+    uint32_t first, last;
+    while (nextChunk(A.work, cursor, first, last)) {
         for (uint32_t unit = first; unit < last; unit++) {
             const uint64_t i = uint64_t(unit) * 64 + lane;
             const bool active = i < S.n;
@@ -770,14 +842,15 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;      // stream work is queued on (own or caller's)
     hipStream_t ownStream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    uint32_t* workCounter = nullptr;          // device
-    unsigned long long* stats = nullptr;      // device, S_COUNT words
+    uint32_t* tickets = nullptr;              // device: kQueues work counters, kQueueStride words apart
+    unsigned long long* stats = nullptr;      // device: kStatSlots copies of the S_COUNT words, kStatStride apart
     int numCUs = 0;
     std::mutex launch;                        // one frame / batch at a time per GPU
     // skip-ahead tables of the driver-level RNG, rebuilt when the frame shape changes
     uint32_t* jump = nullptr;                 // device: kJumpCap words
     int jumpW = -1, jumpH = -1, jumpS = -1, jumpD = -1;
 };
+constexpr size_t kTicketBytes = size_t(kQueues) * kQueueStride * sizeof(uint32_t), kStatBytes = size_t(kStatSlots) * kStatStride * sizeof(unsigned long long);
 constexpr int kJumpMaxDim = 32768, kJumpMaxSamples = 4096, kJumpCap = 2 * kJumpMaxDim + kJumpMaxSamples;
 
 uint64_t hostMulMod(uint64_t a, uint64_t b) { return (a * b) % 2147483647ull; }
@@ -841,29 +914,38 @@ int pickStack(int numLevels)
     return -1;
 }
 
-// Persistent grid: as many 4-wave blocks as a CU can ever hold (8 waves per
-// SIMD).  Blocks beyond what registers / LDS admit simply start when a resident
-// one retires and find the work counter exhausted; no block waits on another.
-int gridFor(const DeviceCtx* c, const void*)
+// Persistent grid: as many 4-wave blocks as the kernel's registers and LDS let
+// the chip hold at once.  No block waits on another, so a smaller share of the
+// chip (a busy GPU) only makes the launch slower, never stuck.
+int gridFor(const DeviceCtx* c, const void* kernel)
 {
-    return c->numCUs * 8;
+    int perCU = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, 0) != hipSuccess || perCU < 1)
+        perCU = 2;
+    if (const char* e = getenv("RTX_GRID_PER_CU"))
+        perCU = std::max(1, atoi(e));
+    return c->numCUs * perCU;
 }
-// units claimed per atomic: enough that the counter is not the bottleneck, few
-// enough that every resident wave still gets ~16 fetches for load balance
-uint32_t chunkFor(const DeviceCtx* c, uint32_t nUnits)
+// Units per claim: small, so that the last chunks of a frame are short, but with
+// enough units that a wave's claim for the next chunk returns before it is needed.
+WorkQueue makeQueue(const DeviceCtx* c, uint32_t nUnits)
 {
-    const uint32_t waves = uint32_t(c->numCUs) * 32u;
-    uint32_t chunk = nUnits / (waves * 16u);
-    if (chunk < 4u)
-        chunk = std::min(4u, std::max(1u, nUnits / waves)); // small launches: still at most nUnits/4 atomics
-    return std::min(64u, chunk);
+    WorkQueue q;
+    q.tickets = c->tickets;
+    q.nUnits = nUnits;
+    const uint32_t waves = uint32_t(c->numCUs) * 16u;
+    q.chunk = std::min(8u, std::max(1u, nUnits / (waves * 32u)));
+    if (const char* e = getenv("RTX_CHUNK"))
+        q.chunk = uint32_t(std::max(1, atoi(e)));
+    q.nChunks = uint32_t((uint64_t(nUnits) + q.chunk - 1) / q.chunk);
+    return q;
 }
 
 template <int STACK>
 int launchTrace(DeviceCtx* c, const TraceArgs& A, bool count)
 {
     const void* k = count ? (const void*)traceKernel<STACK, true> : (const void*)traceKernel<STACK, false>;
-    const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.nUnits / A.chunk + 4) / 4)));
+    const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.work.nChunks + 3) / 4)));
     if (count)
         hipLaunchKernelGGL((traceKernel<STACK, true>), dim3(grid), dim3(kBlock), 0, c->stream, A);
     else
@@ -877,7 +959,7 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, bool full)
 #define RTX_LAUNCH(CNT, FULLV)                                                                                     \
     {                                                                                                              \
         const void* k = (const void*)renderKernel<STACK, CNT, FULLV>;                                              \
-        const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.nUnits / A.chunk + 4) / 4)));                       \
+        const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.work.nChunks + 3) / 4)));                       \
         hipLaunchKernelGGL((renderKernel<STACK, CNT, FULLV>), dim3(grid), dim3(kBlock), 0, c->stream, A);          \
     }
     if (count && full)
@@ -928,8 +1010,12 @@ int fetchStats(DeviceCtx* c, rtx_stats* stats, double t0)
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     {
-        unsigned long long h[S_COUNT];
-        HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> slots(size_t(kStatSlots) * kStatStride);
+        HIP_TRY(hipMemcpy(slots.data(), c->stats, kStatBytes, hipMemcpyDeviceToHost));
+        unsigned long long h[S_COUNT] = {};
+        for (int i = 0; i < kStatSlots; i++)
+            for (int j = 0; j < S_COUNT; j++)
+                h[j] += slots[size_t(i) * kStatStride + j];
         stats->rays_primary = h[S_PRIMARY];
         stats->rays_shadow = h[S_SHADOW];
         stats->rays_bounce = h[S_BOUNCE];
@@ -961,12 +1047,11 @@ int traceImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* d
     A.rays = dRays;
     A.hits = dHits;
     A.n = n;
-    A.nUnits = uint32_t((n + 63) / 64);
-    A.chunk = chunkFor(c, A.nUnits);
-    A.workCounter = c->workCounter;
+    A.work.nUnits = uint32_t((n + 63) / 64);
+    A.work = makeQueue(c, A.work.nUnits);
     A.stats = c->stats;
-    HIP_TRY(hipMemsetAsync(c->workCounter, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * S_COUNT, c->stream));
+    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, kStatBytes, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
         const bool count = wantCounters();
@@ -1064,9 +1149,8 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         setErr("frame too large for one launch");
         return RTX_ERR_LIMIT;
     }
-    A.nUnits = uint32_t(units);
-    A.chunk = chunkFor(c, A.nUnits);
-    A.workCounter = c->workCounter;
+    A.work.nUnits = uint32_t(units);
+    A.work = makeQueue(c, A.work.nUnits);
     A.stats = c->stats;
 
     // the full kernel carries the reflection / transparency / area-light /
@@ -1103,10 +1187,10 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
             c->jumpW = A.W, c->jumpH = A.H, c->jumpS = A.samples, c->jumpD = d;
         }
     }
-    HIP_TRY(hipMemsetAsync(c->workCounter, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * S_COUNT, c->stream));
+    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, kStatBytes, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if (A.nUnits) {
+    if (A.work.nUnits) {
         const bool count = wantCounters();
         switch (stack) {
         case 16: launchRender<16>(c, A, count, full); break;
@@ -1123,7 +1207,8 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
 template <int STACK>
 void launchShade(DeviceCtx* c, const ShadeArgs& S, bool count)
 {
-    const int grid = std::max(1, std::min<int>(gridFor(c, nullptr), int((S.R.nUnits / S.R.chunk + 4) / 4)));
+    const void* k = count ? (const void*)shadeKernel<STACK, true> : (const void*)shadeKernel<STACK, false>;
+    const int grid = std::max(1, std::min<int>(gridFor(c, k), int((S.R.work.nChunks + 3) / 4)));
     if (count)
         hipLaunchKernelGGL((shadeKernel<STACK, true>), dim3(grid), dim3(kBlock), 0, c->stream, S);
     else
@@ -1158,15 +1243,14 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
     A.shadowSamples = p->shadow_samples > 0 ? p->shadow_samples : 50;
     A.glossyRays = p->glossy_rays > 0 ? p->glossy_rays : 5;
     A.seed = p->seed;
-    A.nUnits = uint32_t((n + 63) / 64);
-    A.chunk = chunkFor(c, A.nUnits);
-    A.workCounter = c->workCounter;
+    A.work.nUnits = uint32_t((n + 63) / 64);
+    A.work = makeQueue(c, A.work.nUnits);
     A.stats = c->stats;
     S.rays = dRays;
     S.out = dOut;
     S.n = n;
-    HIP_TRY(hipMemsetAsync(c->workCounter, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * S_COUNT, c->stream));
+    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, kStatBytes, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
         const bool count = wantCounters();
@@ -1211,8 +1295,8 @@ int rtx_init(int device)
         c->stream = c->ownStream;
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev1));
-        HIP_TRY(hipMalloc((void**)&c->workCounter, 256));
-        HIP_TRY(hipMalloc((void**)&c->stats, 256));
+        HIP_TRY(hipMalloc((void**)&c->tickets, kTicketBytes));
+        HIP_TRY(hipMalloc((void**)&c->stats, kStatBytes));
         HIP_TRY(hipMalloc((void**)&c->jump, kJumpCap * sizeof(uint32_t)));
         c->device = device;
     }

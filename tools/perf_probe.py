@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Kernel time of the frame kernel under variations of the headline workload
+(camera distance, samples per pixel, shading on/off), to see where a frame's
+time goes.  Prints one line per variation.  Needs a GPU.
+
+    python tools/perf_probe.py [--reps 5] [--only name,name]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    import torch
+    from raytracer_amd import abi, engine
+    from raytracer_amd.scene import dragon_scene, make_camera, make_params
+
+    hip = engine.hip_lib()
+    scene = dragon_scene()
+    base = dict(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
+    variations = [
+        ("headline", dict(), dict(), dict(samples=16)),
+        ("no shadows", dict(hard_shadow=0), dict(), dict(samples=16)),
+        ("no shading", dict(shading=0, hard_shadow=0), dict(), dict(samples=16)),
+        ("looking away", dict(), dict(look_at=(0.0, 50.0, 0.0)), dict(samples=16)),
+        ("close-up d=1.2", dict(), dict(distance=1.2), dict(samples=16)),
+        ("close-up d=1.2 no shadows", dict(hard_shadow=0), dict(distance=1.2), dict(samples=16)),
+        ("1 spp", dict(), dict(), dict(samples=1)),
+        ("4 spp", dict(), dict(), dict(samples=4)),
+        ("64 spp", dict(), dict(), dict(samples=64)),
+        ("plain driver", dict(), dict(), dict(driver=abi.DRIVER_PLAIN)),
+        ("recursive (general path)", dict(recursive=1), dict(), dict(samples=16)),
+    ]
+    only = [s for s in args.only.split(",") if s]
+    dev = torch.device("cuda", 0)
+    frame = torch.zeros((1080, 1920, 3), dtype=torch.float32, device=dev)
+    gpu = engine.GpuEngine(scene, abi.features(**base))
+    for name, fchg, cchg, pchg in variations:
+        if only and name not in only:
+            continue
+        f = abi.features(**dict(base, **fchg))
+        cam = engine.device_camera(make_camera(**cchg), 1920, 1080)
+        rp = make_params(1920, 1080, **dict(dict(driver=abi.DRIVER_MRAYS), **pchg))
+        st = abi.Stats()
+        best = 1e9
+        for _ in range(args.reps):
+            rc = hip.rtx_render_device(gpu.device_scene(), C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(frame.data_ptr()), C.byref(st))
+            assert rc == 0, hip.rtx_last_error()
+            best = min(best, st.kernel_ms)
+        print(f"{name:28s} {best:8.3f} ms  rays {st.rays/1e6:8.2f} M  shaded {st.shaded_hits/1e6:6.2f} M  {st.rays/best/1e3:9.1f} Mrays/s", flush=True)
+    gpu.close()
+
+
+if __name__ == "__main__":
+    main()
