@@ -245,6 +245,11 @@ RTX_DEV bool pixelOfSequence(const RenderArgs& A, uint32_t q, int& x, int& yTop,
     return true;
 }
 
+// The same within each row of 16 lanes (DPP row_shr:1): lanes 0, 16, 32, 48 receive 0.
+RTX_DEV float fromPreviousLaneOfRow(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
 RTX_DEV float fromLane(float v, int lane) // lane: wave-uniform
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -273,11 +278,26 @@ struct Frame { // one suspended getFinalColor call (src/render.cpp:16-66)
     uint32_t rngBase;
 };
 
-enum PathState { PS_DONE = 0, PS_RADIANCE = 1, PS_SHADOW = 2 };
-enum Phase { PH_NEXT_LIGHT, PH_AFTER_LIGHTS, PH_NEXT_CHILD, PH_RETURN };
+enum PathState { PS_DONE = 0, PS_RADIANCE = 1, PS_SHADOW = 2, PS_AREA = 3 };
+enum Phase { PH_NONE = -1, PH_NEXT_LIGHT, PH_AFTER_LIGHTS, PH_NEXT_CHILD, PH_RETURN };
+
+RTX_DEV float laneValue(float v, int srcLane) { return __shfl(v, srcLane, 64); }
+RTX_DEV V3 laneValue(V3 v, int srcLane) { return mk(__shfl(v.x, srcLane, 64), __shfl(v.y, srcLane, 64), __shfl(v.z, srcLane, 64)); }
 
 // One camera sample from its first ray to its colour.  Every lane of the wave
 // calls this together; lanes without a sample pass active = false.
+//
+// Each lane runs the body of getFinalColor (src/render.cpp:16-66) as a small state
+// machine around ONE traversal site: per iteration of the loop below a lane traces
+// the ray it has in flight (camera / reflection ray, or the shadow ray of a point
+// light), then advances to its next ray.  Segment and parallelogram lights are
+// sampled by the whole wave instead: a lane that reaches such a light parks in
+// PS_AREA, and the next iteration is a cooperative one in which the 64 lanes each
+// take one of the light's samples for that lane's shading point (several points
+// at a time when a light has 32 samples or fewer), trace its shadow ray, and the
+// contributions are added up in sample order along the lanes and handed back.
+// A path's long sequential run of shadow samples thus becomes one traversal step
+// of a full wave, however few lanes of the wave have a shading point.
 template <int STACK, bool COUNT, bool FULL>
 RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD, bool active, uint32_t rngKey, LaneCounters& lc, float firstLimit = kFltMax)
 {
@@ -294,8 +314,8 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     // shading point of the current getFinalColor call
     V3 Ro = ro, Rd = rd, hp = mk(0, 0, 0), visN = mk(0, 0, 0), albedo = mk(0, 0, 0), ks = mk(0, 0, 0), hitN = mk(0, 0, 0);
     float shin = 1.f, Rt = 0.f;
-    V3 Lo = mk(0, 0, 0), avg = mk(0, 0, 0), sh = mk(0, 0, 0), samplePos = mk(0, 0, 0);
-    int li = 0, si = 0;
+    V3 Lo = mk(0, 0, 0), sh = mk(0, 0, 0);
+    int li = 0;
 
     Frame frames[FULL ? kMaxDepth : 1];
     // transparency chain (src/transparency.cpp:6-20): alpha and colour of each
@@ -312,32 +332,146 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     float shadowLimit = kFltMax, shadowStop = -__builtin_inff();
     bool shadowBehind = false;
 
+    // cooperative sampling geometry (wave-uniform): `group` lanes work on one
+    // shading point, perRound points are served per iteration; a light with more
+    // than 64 samples takes several iterations per point (areaRound, areaCarry)
+    const int lane = threadIdx.x & 63;
+    const int nS = A.shadowSamples;
+    const int group = nS < 64 ? nS : 64;
+    const int perRound = 64 / group;
+    const int mySlot = lane / group, mySample = lane - mySlot * group;
+    int areaRound = 0;
+    V3 areaCarry = mk(0, 0, 0);
+
     bool shadedPending = false; // counted at the loop head, where the wave is converged
     bool firstQuery = true;
     while (__any(state != PS_DONE)) {
-        float t = firstQuery ? firstLimit : kFltMax;
-        firstQuery = false;
-        Hit hit;
-        bool any = false;
+        const uint64_t pending = FULL ? __ballot(state == PS_AREA) : 0ull;
+        const bool coop = pending != 0;
         lc.countShaded(shadedPending);
         shadedPending = false;
-        lc.countShadow(state == PS_SHADOW);
-        lc.countPrimary(state == PS_RADIANCE && level == 0);
-        lc.countBounce(state == PS_RADIANCE && level != 0);
+
+        // ---- the ray this lane traces in this iteration
+        V3 qo = ro, qd = rd;
+        float t = kFltMax, qStop = -__builtin_inff(), qLimit = kFltMax;
+        bool trace = false;
+        // cooperative iteration: the shading point this lane samples for
+        uint64_t served = 0;
+        bool worker = false, workerBehind = false;
+        V3 workerHp = mk(0, 0, 0), contribution = mk(0, 0, 0);
+        if (FULL && coop) {
+            int mine = -1;
+            uint64_t m = pending;
+            for (int slot = 0; slot < perRound && m; slot++) {
+                const int p = __builtin_ctzll(m);
+                m &= m - 1;
+                served |= 1ull << p;
+                if (mySlot == slot)
+                    mine = p;
+            }
+            const int sampleIndex = areaRound * 64 + mySample;
+            worker = mine >= 0 && sampleIndex < nS;
+            const int src = mine >= 0 ? mine : 0;
+            workerHp = laneValue(hp, src);
+            const V3 pRd = laneValue(Rd, src), pN = laneValue(hitN, src), pAlbedo = laneValue(albedo, src), pKs = laneValue(ks, src), pVisN = laneValue(visN, src);
+            const float pShin = laneValue(shin, src);
+            const uint32_t pKey = uint32_t(__shfl(int(rngKey), src, 64)), pCounter = uint32_t(__shfl(int(counter), src, 64));
+            const int srcLight = __shfl(li, src, 64); // every lane takes part: the source lane need not be a worker
+            const int pLight = worker ? srcLight : 0;
+            lc.countShadow(worker);
+            if (worker) {
+                const rtx_light& L = sc.lights[pLight];
+                V3 pos, col;
+                if (L.type == RTX_LIGHT_SEGMENT) {
+                    // src/light.cpp:26-32
+                    const V3 e0 = mk(L.p[0]), e1 = mk(L.p[1]);
+                    const float a = keyedUniform(pKey, pCounter + uint32_t(sampleIndex));
+                    pos = a * (e1 - e0) + e0;
+                    col = (1 - a) * mk(L.c[0]) + a * mk(L.c[1]);
+                } else {
+                    // src/light.cpp:36-45
+                    const float a1 = keyedUniform(pKey, pCounter + 2u * uint32_t(sampleIndex));
+                    const V3 c1 = (1 - a1) * mk(L.c[0]) + a1 * mk(L.c[1]);
+                    const V3 c2 = (1 - a1) * mk(L.c[2]) + a1 * mk(L.c[3]);
+                    const float a2 = keyedUniform(pKey, pCounter + 2u * uint32_t(sampleIndex) + 1u);
+                    col = (1 - a2) * c1 + a2 * c2;
+                    pos = mk(L.p[0]) + mk(L.p[1]) * a1 + mk(L.p[2]) * a2;
+                }
+                contribution = phong(pos, col, workerHp, pRd, pN, pAlbedo, pKs, pShin);
+                workerBehind = dot(normalize(pos - workerHp), normalize(pVisN)) < -1e-6f;
+                qo = pos;
+                qd = workerHp - pos;
+                const float len = length(qd);
+                const float scale = fmaxf(fmaxf(fmaxf(fabsf(workerHp.x), fabsf(workerHp.y)), fabsf(workerHp.z)), fmaxf(fmaxf(fabsf(pos.x), fabsf(pos.y)), fabsf(pos.z)));
+                const bool shorten = len >= 0.2f && scale <= 64.0f;
+                qLimit = shorten ? 1.01f : kFltMax;
+                qStop = shorten ? 1.0f - 4e-3f / len : -__builtin_inff();
+                trace = !workerBehind;
+            }
+        } else {
+            if (firstQuery)
+                t = firstLimit;
+            lc.countShadow(state == PS_SHADOW);
+            lc.countPrimary(state == PS_RADIANCE && level == 0);
+            lc.countBounce(state == PS_RADIANCE && level != 0);
+            trace = state == PS_RADIANCE || (state == PS_SHADOW && !shadowBehind);
+            if (state == PS_SHADOW) {
+                qStop = shadowStop;
+                qLimit = shadowLimit;
+            }
+            firstQuery = false;
+        }
+
+        // ---- the one traversal site
+        Hit hit;
+        bool any = false;
         {
             int bestK = -1, sphere = -1;
             V3 sphereN = mk(0, 0, 0);
-            if (state == PS_RADIANCE || (state == PS_SHADOW && !shadowBehind))
-                any = closestHit<STACK, COUNT, true>(sc, st, f, ro, rd, t, bestK, sphere, sphereN, lc.tc, state == PS_SHADOW ? shadowStop : -__builtin_inff(), state == PS_SHADOW ? shadowLimit : kFltMax);
-            if (state == PS_RADIANCE)
+            if (trace)
+                any = closestHit<STACK, COUNT, true>(sc, st, f, qo, qd, t, bestK, sphere, sphereN, lc.tc, qStop, qLimit);
+            if (!coop && state == PS_RADIANCE)
                 hitAttributes(sc, f, ro, rd, t, bestK, sphere, sphereN, hit);
         }
-        if (state == PS_DONE)
-            continue;
 
-        int phase;
+        int phase = PH_NONE;
         V3 value = mk(0, 0, 0);
-        if (state == PS_SHADOW) {
+        if (FULL && coop) {
+            // testVisibilityLightSample (src/light.cpp:70-102) for this lane's sample, then
+            // `avg += contribution` in sample order (src/light.cpp:160-163, 173-176)
+            const V3 second = qo + t * qd;
+            const float vis = (workerBehind || double(distance(workerHp, second)) > 1e-3) ? 0.0f : 1.0f;
+            const V3 c = contribution * vis;
+            const int cnt = min(group, nS - areaRound * 64);
+            const bool head = mySample == 0;
+            float rx = head ? areaCarry.x + c.x : c.x, ry = head ? areaCarry.y + c.y : c.y, rz = head ? areaCarry.z + c.z : c.z;
+            for (int j = 1; j < cnt; j++) {
+                const float nx = fromPreviousLane(rx) + c.x, ny = fromPreviousLane(ry) + c.y, nz = fromPreviousLane(rz) + c.z;
+                rx = head ? rx : nx;
+                ry = head ? ry : ny;
+                rz = head ? rz : nz;
+            }
+            if ((areaRound + 1) * 64 < nS) {
+                // more samples of the same point to come (one point per iteration here)
+                areaCarry = mk(fromLane(rx, cnt - 1), fromLane(ry, cnt - 1), fromLane(rz, cnt - 1));
+                areaRound++;
+            } else {
+                // the k-th served lane finds its sum in the last lane of group k
+                const int k = __popcll(served & ((1ull << lane) - 1ull));
+                const int from = min(k * group + cnt - 1, 63);
+                const V3 avg = mk(__shfl(rx, from, 64), __shfl(ry, from, 64), __shfl(rz, from, 64));
+                if ((served >> lane) & 1ull) {
+                    const rtx_light& L = sc.lights[li];
+                    Lo = Lo + avg * float(1.0 / double(float(nS)));
+                    counter += (L.type == RTX_LIGHT_SEGMENT ? 1u : 2u) * uint32_t(nS);
+                    li++;
+                    state = PS_RADIANCE; // left again below
+                    phase = PH_NEXT_LIGHT;
+                }
+                areaRound = 0;
+                areaCarry = mk(0, 0, 0);
+            }
+        } else if (state == PS_SHADOW) {
             // testVisibilityLightSample, src/light.cpp:70-102: the shadow ray runs
             // from the light sample to the shading point (un-normalised direction)
             // and must end within 1e-3 of it; a ray that hits nothing counts as blocked
@@ -347,21 +481,10 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                 vis = 0.0f;
             else if (double(distance(hp, second)) > 1e-3)
                 vis = 0.0f;
-            const rtx_light& L = sc.lights[li];
-            if (L.type == RTX_LIGHT_POINT) {
-                Lo = Lo + sh * vis;
-                li++;
-            } else {
-                avg = avg + sh * vis;
-                si++;
-                if (si == A.shadowSamples) {
-                    Lo = Lo + avg * float(1.0 / double(float(A.shadowSamples)));
-                    si = 0;
-                    li++;
-                }
-            }
+            Lo = Lo + sh * vis;
+            li++;
             phase = PH_NEXT_LIGHT;
-        } else {
+        } else if (state == PS_RADIANCE) {
             // result of a radiance ray = body of getFinalColor
             if (transparencyDriver && level == 0) {
                 const float alpha = (any && hit.material >= 0) ? sc.mats[hit.material].transparency : 1.0f;
@@ -391,70 +514,46 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                     visN = (dot(normalize(hitN), normalize(Ro - hp)) < -1e-6f) ? -hitN : hitN;
                     Lo = mk(0, 0, 0);
                     li = 0;
-                    si = 0;
                     phase = PH_NEXT_LIGHT;
                 }
             }
         }
 
-        // advance until the next ray is in flight or the sample is finished
-        bool launched = false;
+        // advance until the next ray is in flight, the lane waits for the wave to
+        // sample an area light, or the sample is finished
+        bool launched = phase == PH_NONE;
         while (!launched) {
             if (phase == PH_NEXT_LIGHT) {
                 // computeLightContribution, src/light.cpp:139-189
                 phase = PH_AFTER_LIGHTS;
                 while (li < sc.nLights) {
                     const rtx_light& L = sc.lights[li];
-                    V3 pos, col;
-                    bool sample = false;
                     if (L.type == RTX_LIGHT_POINT) {
-                        pos = mk(L.p[0]);
-                        col = mk(L.c[0]);
+                        const V3 pos = mk(L.p[0]), col = mk(L.c[0]);
                         if (!f.enable_hard_shadow) {
                             Lo = Lo + phong(pos, col, hp, Rd, hitN, albedo, ks, shin);
                             li++;
                             continue;
                         }
-                        sample = true;
-                    } else if (FULL && f.enable_soft_shadow) {
-                        if (si == 0)
-                            avg = mk(0, 0, 0);
-                        if (L.type == RTX_LIGHT_SEGMENT) {
-                            // src/light.cpp:26-32
-                            const V3 e0 = mk(L.p[0]), e1 = mk(L.p[1]);
-                            const float a = keyedUniform(rngKey, counter++);
-                            pos = a * (e1 - e0) + e0;
-                            col = (1 - a) * mk(L.c[0]) + a * mk(L.c[1]);
-                        } else {
-                            // src/light.cpp:36-45
-                            const float a1 = keyedUniform(rngKey, counter++);
-                            const V3 c1 = (1 - a1) * mk(L.c[0]) + a1 * mk(L.c[1]);
-                            const V3 c2 = (1 - a1) * mk(L.c[2]) + a1 * mk(L.c[3]);
-                            const float a2 = keyedUniform(rngKey, counter++);
-                            col = (1 - a2) * c1 + a2 * c2;
-                            pos = mk(L.p[0]) + mk(L.p[1]) * a1 + mk(L.p[2]) * a2;
-                        }
-                        sample = true;
-                    }
-                    if (!sample) {
-                        li++;
-                        continue;
-                    }
-                    sh = phong(pos, col, hp, Rd, hitN, albedo, ks, shin);
-                    samplePos = pos;
-                    ro = pos;
-                    rd = hp - pos;
-                    shadowBehind = dot(normalize(pos - hp), normalize(visN)) < -1e-6f;
-                    {
+                        sh = phong(pos, col, hp, Rd, hitN, albedo, ks, shin);
+                        ro = pos;
+                        rd = hp - pos;
+                        shadowBehind = dot(normalize(pos - hp), normalize(visN)) < -1e-6f;
                         const float len = length(rd);
                         const float scale = fmaxf(fmaxf(fmaxf(fabsf(hp.x), fabsf(hp.y)), fabsf(hp.z)), fmaxf(fmaxf(fabsf(pos.x), fabsf(pos.y)), fabsf(pos.z)));
                         const bool shorten = len >= 0.2f && scale <= 64.0f;
                         shadowLimit = shorten ? 1.01f : kFltMax;
                         shadowStop = shorten ? 1.0f - 4e-3f / len : -__builtin_inff();
+                        state = PS_SHADOW;
+                        launched = true;
+                        break;
                     }
-                    state = PS_SHADOW;
-                    launched = true;
-                    break;
+                    if (FULL && f.enable_soft_shadow && A.shadowSamples > 0) {
+                        state = PS_AREA; // sampled by the whole wave in the next iteration
+                        launched = true;
+                        break;
+                    }
+                    li++; // segment / parallelogram lights only count with soft shadows (src/light.cpp:154,167)
                 }
                 if (launched)
                     break;
@@ -636,6 +735,7 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
     while (nextChunk(A.work, cursor, firstUnit, lastUnit)) {
         for (uint32_t unit = firstUnit; unit < lastUnit; unit++) {
         V3 accum = mk(0, 0, 0);
+        uint32_t storeIndex = 0xffffffffu; // where this lane's pixel goes in the output; ~0: nowhere
         V3 carry = mk(0, 0, 0); // sum of the rounds so far (a pixel with more than 64 samples owns the wave)
         for (int round = 0; round < A.rounds; round++) {
             const int sample = round * A.lanesPerPixel + sub;
@@ -643,9 +743,8 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
             bool active = false;
             uint32_t key = 0;
             {
-                // the pixel's coordinates are only needed to make the camera ray; they
-                // are derived again for the store below rather than kept in registers
-                // across the traversal loops
+                // the pixel's coordinates are only needed to make the camera ray; only the
+                // output index is kept across the traversal loops
                 int x = 0, yTop = 0;
                 uint32_t outIndex = 0;
                 const bool pixelOk = laneUsed && pixelOfSequence(A, unit * uint32_t(A.pixelsPerUnit) + uint32_t(slot), x, yTop, outIndex);
@@ -654,6 +753,8 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                 // pixel corner, not centre (src/render.cpp:76-79)
                 const float ndcX = float(x) / float(A.W) * 2.0f - 1.0f, ndcY = float(y) / float(A.H) * 2.0f - 1.0f;
                 active = pixelOk && sample < A.samples;
+                if (pixelOk)
+                    storeIndex = outIndex;
                 if (FULL)
                     key = sampleKey(A.seed, pixelIndex, uint32_t(sample));
                 if (active) {
@@ -714,6 +815,17 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                 // (selects written per component: a select between two V3 objects is
                 // lowered to an indexed copy through scratch memory)
                 float rx = head ? carry.x + c.x : c.x, ry = head ? carry.y + c.y : c.y, rz = head ? carry.z + c.z : c.z;
+                if (A.lanesPerPixel == 16) {
+                    // a pixel's samples fill one DPP row: shifting within the row feeds the
+                    // head lane the 0 the chain starts from, so no select is needed
+                    rx = ry = rz = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        rx = fromPreviousLaneOfRow(rx) + c.x;
+                        ry = fromPreviousLaneOfRow(ry) + c.y;
+                        rz = fromPreviousLaneOfRow(rz) + c.z;
+                    }
+                } else
                 for (int j = 1; j < n; j++) {
                     const float nx = fromPreviousLane(rx) + c.x, ny = fromPreviousLane(ry) + c.y, nz = fromPreviousLane(rz) + c.z;
                     rx = head ? rx : nx;
@@ -730,14 +842,9 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                 }
             }
         }
-        if (writer) {
-            // an opaque copy of the unit number keeps the compiler from carrying the
-            // coordinates computed before the traversal all the way down here
-            uint32_t unitAgain = unit;
-            asm volatile("" : "+s"(unitAgain));
-            int x = 0, yTop = 0;
-            uint32_t outIndex = 0;
-            if (pixelOfSequence(A, unitAgain * uint32_t(A.pixelsPerUnit) + uint32_t(slot), x, yTop, outIndex)) {
+        if (writer && storeIndex != 0xffffffffu) {
+            {
+                const uint32_t outIndex = storeIndex;
                 V3 px = accum;
                 if (A.driver == RTX_DRIVER_MRAYS) {
                     const float inv = 1.0f / (float(A.samples) * 1.0f);
@@ -880,6 +987,7 @@ struct rtx_scene {
     int nBuffers = 0;
     int numLevels = 0;
     bool hasEnv = false;
+    bool hasAreaLight = false; // a segment or parallelogram light
 };
 
 namespace {
@@ -1142,6 +1250,11 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.out = dOut;
     A.lanesPerPixel = std::min(A.samples, 64);
     A.pixelsPerUnit = 64 / A.lanesPerPixel;
+    // With area lights every shading point costs the wave a traversal step per 64
+    // light samples however few camera samples it carries, so a unit holds few
+    // pixels: short units balance better and their camera rays are the small part.
+    if (f->enable_soft_shadow && scene->hasAreaLight && A.shadowSamples >= 16)
+        A.pixelsPerUnit = std::min(A.pixelsPerUnit, 8);
     A.rounds = (A.samples + 63) / 64;
     const uint64_t seqPixels = uint64_t(g.tilesMine) * g.ts * g.ts;
     const uint64_t units = (seqPixels + A.pixelsPerUnit - 1) / A.pixelsPerUnit;
@@ -1414,6 +1527,8 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     s->d.env = d->envmap;
     s->d.nTris = int32_t(d->n_tris);
     s->d.nLights = int32_t(d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; i++)
+        s->hasAreaLight = s->hasAreaLight || d->lights[i].type != RTX_LIGHT_POINT;
     s->d.nSpheres = int32_t(d->n_spheres);
     s->d.nMaterials = int32_t(d->n_materials);
     s->d.rootRef = d->root_ref;

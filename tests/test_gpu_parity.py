@@ -132,6 +132,30 @@ def test_get_final_color_matches_reference_and_oracle(gpu_device, golden_shade):
         assert_images_close(got, golden_shade[name], name + " vs reference")
 
 
+@pytest.mark.parametrize("samples", [1, 3, 16, 50, 64, 100, 130])
+def test_area_light_sample_counts(gpu_device, samples):
+    """Segment and parallelogram lights are sampled by the whole wave: sample
+    counts that pack several shading points into one wave step (<= 32), leave
+    lanes idle (50), fill the wave (64) and need several steps per point (> 64)."""
+    scene = cases.load_scene("cornell")
+    scene.lights = [abi.segment_light((0.3, 0.55, -0.2), (-0.3, 0.55, 0.2), (0.9, 0.2, 0.1), (0.2, 1, 0.3)),
+                    abi.point_light((0.0, 0.5, 0.3), (0.3, 0.3, 0.3))] + list(cases._AREA)
+    f = abi.features(**dict(cases.BASE, soft_shadow=1, recursive=1, glossy_reflection=1))
+    cam = make_camera()
+    rp = make_params(40, 30, shadow_samples=samples, glossy_rays=2, ray_depth=1)
+    gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+    got = gpu.render(cam, f, rp)
+    rays_gpu = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
+    want = orc.render(cam, f, rp)
+    assert rays_gpu == tuple(int(x) for x in orc.counters[:3])
+    assert_images_close(got, want, f"{samples} samples per area light")
+    # multi-sample driver on top: 4 camera samples per pixel share a wave with the light samples
+    rp = make_params(24, 18, driver=abi.DRIVER_MRAYS, samples=4, shadow_samples=samples, glossy_rays=2, ray_depth=1)
+    assert_images_close(gpu.render(cam, f, rp), orc.render(cam, f, rp), f"{samples} samples per area light, 4 spp")
+    gpu.close()
+    orc.close()
+
+
 def test_shadow_query_shortcuts_do_not_change_frames(gpu_device):
     """The shortened shadow queries must give the reference's answer in the regimes
     where they switch on and off: light closer than 0.2 to surfaces, coordinates

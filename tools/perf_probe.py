@@ -39,24 +39,47 @@ def main():
         ("plain driver", dict(), dict(), dict(driver=abi.DRIVER_PLAIN)),
         ("recursive (general path)", dict(recursive=1), dict(), dict(samples=16)),
     ]
+    # configs[2]-like: one parallelogram light, soft shadows, glossy reflections (general kernel)
+    area = [abi.parallelogram_light((-0.2, 0.9, 0.0), (0.4, 0, 0), (0, 0, 0.4), (1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1))]
+    variations += [
+        ("area light 64 samples", dict(soft_shadow=1, hard_shadow=0), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, ray_depth=0), area),
+        ("area 64 + glossy depth 2", dict(soft_shadow=1, hard_shadow=0, recursive=1, glossy_reflection=1), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=2), area),
+        ("mirror depth 4", dict(recursive=1), dict(), dict(driver=abi.DRIVER_PLAIN, ray_depth=4), None),
+        ("transparency driver", dict(), dict(), dict(driver=abi.DRIVER_TRANSPARENCY), None),
+        ("dof 16 samples", dict(), dict(), dict(driver=abi.DRIVER_DOF, samples=16), None),
+    ]
     only = [s for s in args.only.split(",") if s]
     dev = torch.device("cuda", 0)
     frame = torch.zeros((1080, 1920, 3), dtype=torch.float32, device=dev)
     gpu = engine.GpuEngine(scene, abi.features(**base))
-    for name, fchg, cchg, pchg in variations:
+    area_scene = dragon_scene()
+    area_scene.lights = area
+    for m in area_scene.meshes:   # a glossy material: ks != 0, shininess 50
+        m.material[3:6] = 0.5
+        m.material[6] = 50.0
+    gpu_area = None
+    for var in variations:
+        name, fchg, cchg, pchg = var[:4]
         if only and name not in only:
             continue
+        use = gpu
+        if len(var) > 4 and var[4] is not None:
+            if gpu_area is None:
+                gpu_area = engine.GpuEngine(area_scene, abi.features(**base))
+            use = gpu_area
         f = abi.features(**dict(base, **fchg))
         cam = engine.device_camera(make_camera(**cchg), 1920, 1080)
         rp = make_params(1920, 1080, **dict(dict(driver=abi.DRIVER_MRAYS), **pchg))
         st = abi.Stats()
         best = 1e9
         for _ in range(args.reps):
-            rc = hip.rtx_render_device(gpu.device_scene(), C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(frame.data_ptr()), C.byref(st))
+            rc = hip.rtx_render_device(use.device_scene(), C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(frame.data_ptr()), C.byref(st))
             assert rc == 0, hip.rtx_last_error()
             best = min(best, st.kernel_ms)
         print(f"{name:28s} {best:8.3f} ms  rays {st.rays/1e6:8.2f} M  shaded {st.shaded_hits/1e6:6.2f} M  {st.rays/best/1e3:9.1f} Mrays/s", flush=True)
     gpu.close()
+    if gpu_area is not None:
+        gpu_area.close()
 
 
 if __name__ == "__main__":
