@@ -149,6 +149,32 @@ class _Engine:
                               int(bilinear), _ptr(dirs), len(dirs), _ptr(out))
         return out
 
+    def kat_env_bins(self, image, cap=4096):
+        image = np.ascontiguousarray(image, np.float32)
+        out = np.zeros((cap, 4), np.float32)
+        fn = self.fn("kat_env_bins")
+        fn.restype = C.c_int
+        n = fn(_ptr(image), image.shape[1], image.shape[0], _ptr(out), cap)
+        assert n <= cap
+        return out[:n].copy()
+
+    def kat_sample2d(self, rect, h, k, seed, pixel, index):
+        rect = np.asarray(rect, np.float32)
+        out = np.zeros((h * k, 2), np.float32)
+        self.fn("kat_sample2d")(_ptr(rect), int(h), int(k), C.c_uint32(seed), C.c_uint32(pixel), C.c_uint32(index), _ptr(out))
+        return out
+
+    def kat_env_rays(self, image, mapping, vfov_degrees, position, normal, n, seed, pixel, cap=4096):
+        image = np.ascontiguousarray(image, np.float32)
+        pos, nrm = np.asarray(position, np.float32), np.asarray(normal, np.float32)
+        out = np.zeros(cap, abi.RAY_DTYPE)
+        fn = self.fn("kat_env_rays")
+        fn.restype = C.c_int
+        cnt = fn(_ptr(image), image.shape[1], image.shape[0], int(mapping), C.c_float(vfov_degrees), _ptr(pos), _ptr(nrm), int(n),
+                 C.c_uint32(seed), C.c_uint32(pixel), _ptr(out), cap)
+        assert cnt <= cap
+        return out[:cnt].copy()
+
     def kat_light_samples(self, light, seed, pixel, n):
         pos, col = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
         self.fn("kat_light_samples")(C.byref(light), C.c_uint32(seed), C.c_uint32(pixel), n, _ptr(pos), _ptr(col))

@@ -139,6 +139,10 @@ struct Scene {
     std::vector<rtx_light> lights;
     rtx_envmap env { -1, RTX_ENV_SPHERICAL, 1.f, { 0, 0, 0 } };
     bool hasEnv = false;
+    struct Rect {
+        float lx, ly, ux, uy; // AxisAlignedRectangle lower / upper (src/common.h:33-36)
+    };
+    std::vector<Rect> envBins; // EnvironmentMap::radianceBins
     // BVH
     std::vector<Pair> pairs;
     std::vector<Node> nodes;
@@ -195,6 +199,66 @@ struct PixelRng {
     }
     float next() { return keyedUniform(key, counter++); }
 };
+
+// ---- what libstdc++ 11 (the library the reference is built against here) makes
+// of the engine the keyed stream stands in for.  sample2D (src/sampling.cpp:6-60)
+// seeds ONE engine from a random_device draw and then calls std::shuffle and
+// uniform_real_distribution on it, so the engine's later outputs matter: output
+// m of the engine made from draw index `index` is bits(index) for m = 0 and
+// mix32(bits(index) + m + 1) after that (oracle/ref_harness/rng_shim.h).
+struct DrawEngine {
+    uint32_t base, m = 0;
+    DrawEngine(uint32_t key, uint32_t index) : base(mix32(key ^ (index * 0x85ebca77u) ^ 0x68bc21ebu)) {}
+    uint32_t operator()()
+    {
+        const uint32_t v = m == 0 ? base : mix32(base + m + 1u);
+        m++;
+        return v;
+    }
+};
+// std::uniform_int_distribution<unsigned long>{0, range - 1} on a 32-bit engine:
+// Lemire's nearly divisionless method (bits/uniform_int_dist.h, _S_nd)
+inline uint32_t uniformBelow(DrawEngine& g, uint32_t range)
+{
+    uint64_t product = uint64_t(g()) * uint64_t(range);
+    uint32_t low = uint32_t(product);
+    if (low < range) {
+        const uint32_t threshold = uint32_t(-range) % range;
+        while (low < threshold) {
+            product = uint64_t(g()) * uint64_t(range);
+            low = uint32_t(product);
+        }
+    }
+    return uint32_t(product >> 32);
+}
+// std::shuffle (bits/stl_algo.h): two swap positions per engine call
+template <class T>
+void stdShuffle(T* a, uint32_t n, DrawEngine& g)
+{
+    if (n == 0)
+        return;
+    uint32_t i = 1;
+    if (n % 2 == 0) {
+        std::swap(a[i], a[uniformBelow(g, 2)]);
+        i++;
+    }
+    while (i != n) {
+        const uint32_t swapRange = i + 1;
+        const uint32_t x = uniformBelow(g, swapRange * (swapRange + 1));
+        std::swap(a[i], a[x / (swapRange + 1)]);
+        i++;
+        std::swap(a[i], a[x % (swapRange + 1)]);
+        i++;
+    }
+}
+// uniform_real_distribution<float>(0, 1) on the same engine: one output / 2^32
+inline float uniformReal(DrawEngine& g)
+{
+    float u = float(g()) / 4294967296.0f;
+    if (u >= 1.0f)
+        u = 0.99999994f;
+    return u;
+}
 
 // std::default_random_engine = minstd_rand0 (x <- 16807 x mod 2^31-1, seed 1),
 // consumed as one sequential stream by the reference's single-thread drivers
@@ -718,6 +782,109 @@ V3 computeShading(const Scene& s, V3 lightPos, V3 lightColor, const Feat& f, con
     return lightColor * mat.kd * ndl + specular;
 }
 
+// ---------------------------------------- environment light sampling ----
+// getRadiance, src/environment_mapping.cpp:26-29 (double arithmetic, float result)
+inline float radianceOf(V3 c) { return float(0.25 * (double(c.x) + 2. * double(c.y) + double(c.z))); }
+
+// EnvironmentMap::buildRadianceHierarchy, src/environment_mapping.cpp:55-105
+void buildRadianceBins(Scene& s, const Texture& t, Scene::Rect aar, float totalRadiance)
+{
+    const int W = t.w[0], H = t.h[0];
+    const float sizeX = aar.ux - aar.lx, sizeY = aar.uy - aar.ly;
+    const float minRadiance = float((W * H) / 1000);
+    if (totalRadiance < minRadiance || double(sizeX + sizeY) < 0.1) {
+        s.envBins.push_back(aar);
+        return;
+    }
+    const float imageW = float(W), m1x = float(W - 1), m1y = float(H - 1);
+    const bool splitVertically = sizeY / sizeX > 1.f;
+    const float splitX = splitVertically ? aar.ux : float(0.5 * double(aar.lx + aar.ux));
+    const float splitY = splitVertically ? float(0.5 * double(aar.ly + aar.uy)) : aar.uy;
+    const float lowerScaledX = aar.lx * m1x, lowerScaledY = aar.ly * m1y;
+    const float splitScaledX = splitX * m1x, splitScaledY = splitY * m1y;
+    float lowerHalf = 0.f;
+    for (int i = int(lowerScaledX); float(i) < splitScaledX; i++)
+        for (int j = int(lowerScaledY); float(j) < splitScaledY; j++)
+            lowerHalf += radianceOf(t.pix[0][size_t(float(i) + float(j) * imageW)]);
+    const float upperHalf = totalRadiance - lowerHalf;
+    const Scene::Rect lower { aar.lx, aar.ly, splitX, splitY };
+    const Scene::Rect upper { splitVertically ? aar.lx : splitX, splitVertically ? splitY : aar.ly, aar.ux, aar.uy };
+    if (double(lowerHalf) > 0.5 * double(totalRadiance))
+        buildRadianceBins(s, t, lower, lowerHalf);
+    else
+        s.envBins.push_back(lower);
+    if (double(upperHalf) > 0.5 * double(totalRadiance))
+        buildRadianceBins(s, t, upper, upperHalf);
+    else
+        s.envBins.push_back(upper);
+}
+// EnvironmentMap's constructor, src/environment_mapping.cpp:42-53
+void buildRadianceBins(Scene& s)
+{
+    s.envBins.clear();
+    if (s.env.texture < 0)
+        return;
+    const Texture& t = s.textures[size_t(s.env.texture)];
+    float total = 0.f;
+    for (const V3& px : t.pix[0])
+        total += radianceOf(px);
+    buildRadianceBins(s, t, Scene::Rect { 0.f, 0.f, 1.f, 1.f }, total);
+}
+
+// sample2D, src/sampling.cpp:6-60: multi-jittered samples of a rectangle; the engine
+// is seeded from draw `index` of the keyed stream.  out: h*k (x, y) pairs.
+void sample2D(const Scene::Rect& rect, int h, int k, uint32_t key, uint32_t index, std::vector<float>& out)
+{
+    DrawEngine urng(key, index);
+    std::vector<int> shufflingIndices(static_cast<size_t>(h));
+    for (int i = 0; i < h; i++)
+        shufflingIndices[size_t(i)] = i;
+    struct Cell {
+        float x, y;
+    };
+    std::vector<std::vector<Cell>> rows(static_cast<size_t>(k), std::vector<Cell>(static_cast<size_t>(h)));
+    for (int j = 0; j < k; j++)
+        for (int i = 0; i < h; i++)
+            rows[size_t(j)][size_t(i)] = Cell { float(j), float(i) };
+    for (int j = 0; j < k; j++)
+        stdShuffle(rows[size_t(j)].data(), uint32_t(h), urng);
+    for (int i = 0; i < h; i++) {
+        stdShuffle(shufflingIndices.data(), uint32_t(h), urng);
+        int j = 0;
+        const Cell temp = rows[size_t(j)][size_t(i)];
+        for (int x = 0; x < k; x++) {
+            rows[size_t(j)][size_t(i)] = rows[size_t(shufflingIndices[size_t(x)])][size_t(i)];
+            j = shufflingIndices[size_t(x)];
+        }
+        rows[size_t(j)][size_t(i)] = temp;
+    }
+    const float scaleX = float(1. / (k + 1)), scaleY = float(1. / (h + 1));
+    const float sizeX = rect.ux - rect.lx, sizeY = rect.uy - rect.ly;
+    out.clear();
+    for (int j = 0; j < k; j++)
+        for (int i = 0; i < h; i++) {
+            const Cell c = rows[size_t(j)][size_t(i)];
+            const float jx = uniformReal(urng);
+            const float jy = uniformReal(urng);
+            const float subX = c.x + jx, subY = c.y + jy;
+            out.push_back(rect.lx + sizeX * (float(i / (h + 1.)) + scaleX * subX));
+            out.push_back(rect.ly + sizeY * (float(j / (k + 1.)) + scaleY * subY));
+        }
+}
+
+// EnvironmentMap::getRayForCoordinate, src/environment_mapping.cpp:130-165
+V3 envDirection(const Scene& s, float cx, float cy)
+{
+    const float azimuth = float(2.0 * kPi * (double(cx) - 0.5));
+    float pitch;
+    if (s.env.mapping == RTX_ENV_SPHERICAL)
+        pitch = float((0.5 - double(cy)) * double(s.env.vfov_radians));
+    else
+        pitch = float(std::atan(double(std::tan(0.5f * s.env.vfov_radians)) * (0.5 - double(cy)) / 0.5));
+    const float px = std::cos(pitch), py = std::sin(pitch);
+    return mk(px * std::cos(azimuth), py, px * std::sin(azimuth));
+}
+
 struct Ctx {
     const Scene& s;
     Feat f;
@@ -758,6 +925,58 @@ float visibility(Ctx& cx, V3 samplePos, const Ray& ray, const Hit& hit)
     if (double(distance(hp, second)) > 1e-3)
         return 0.0f;
     return 1.0f;
+}
+
+// EnvironmentMap::getSamplingRay, src/environment_mapping.cpp:107-128: rays towards
+// samples of randomly chosen radiance bins, kept when they leave the surface
+void envSamplingRays(Ctx& cx, V3 position, V3 normal, int n, std::vector<Ray>& out)
+{
+    const Scene& s = cx.s;
+    out.clear();
+    if (s.env.texture < 0) {
+        Ray r;
+        r.o = position;
+        r.d = normal;
+        r.t = kFltMax;
+        out.push_back(r);
+        return;
+    }
+    const int nPerTry = int(std::max(std::sqrt(n / 10.), 1.));
+    std::vector<float> samples;
+    for (int i = 0; int(out.size()) < n && i < 100; i++) {
+        const int randomBin = int(std::floor(cx.rng.next() * float(s.envBins.size())));
+        const Scene::Rect& rect = s.envBins[size_t(randomBin)];
+        sample2D(rect, nPerTry, nPerTry, cx.rng.key, cx.rng.counter++, samples);
+        for (size_t k = 0; k + 1 < samples.size(); k += 2) {
+            Ray r;
+            r.d = envDirection(s, samples[k], samples[k + 1]);
+            const float eps = 0.0001f / dot(normalize(r.d), normal);
+            r.o = position + eps * r.d;
+            r.t = kFltMax;
+            if (dot(r.d, normal) > 0.f)
+                out.push_back(r);
+        }
+    }
+}
+
+// src/light.cpp:47-66
+V3 sampleEnvironment(Ctx& cx, const Ray& ray, const Hit& hit)
+{
+    V3 avg = mk(0, 0, 0);
+    const V3 origin = ray.o + ray.t * ray.d;
+    Hit mine = hit;
+    mine.normal = dot(hit.normal, ray.d) < 0 ? hit.normal : -hit.normal;
+    std::vector<Ray> srays;
+    envSamplingRays(cx, origin, mine.normal, cx.shadowSamples, srays);
+    for (Ray& sray : srays) {
+        Hit dummy;
+        if (!cx.f.hardShadow || !trace(cx, sray, dummy, kShadow)) {
+            const V3 pos = sray.o + 100000.f * sray.d;
+            const V3 col = envColor(cx.s, sray, cx.f);
+            avg = avg + computeShading(cx.s, pos, col, cx.f, ray, mine);
+        }
+    }
+    return avg * float(1.0 / double(float(cx.shadowSamples)));
 }
 
 // src/light.cpp:139-189 with the samplers of src/light.cpp:26-45
@@ -808,7 +1027,8 @@ V3 lightContribution(Ctx& cx, const Ray& ray, const Hit& hit)
             }
         }
     }
-    // sampleEnvironment (src/light.cpp:47-66,179-180) is outside this restatement
+    if (cx.f.softShadow && cx.f.envMap && s.hasEnv)
+        med = med + sampleEnvironment(cx, ray, hit);
     return med;
 }
 
@@ -1091,6 +1311,7 @@ void orc_scene_set_envmap(void* p, const float* rgb, int w, int h, int mapping, 
     s.env.mapping = mapping;
     s.env.vfov_radians = vfovDegrees * float(0.01745329251994329576923690768489); // glm::radians
     std::memcpy(s.env.background, bg, 3 * sizeof(float));
+    buildRadianceBins(s);
     s.hasEnv = true;
 }
 
@@ -1339,6 +1560,44 @@ void orc_kat_envmap(const float* rgb, int w, int h, int mapping, float vfovDegre
         r.d = mk(dirs + 3 * i);
         put(out + 3 * i, envColor(s, r, f));
     }
+}
+// radiance bins of an environment image: up to cap rectangles (lx, ly, ux, uy); returns their number
+int orc_kat_env_bins(const float* rgb, int w, int h, float* out, int cap)
+{
+    Scene s;
+    const float bg[3] = { 0, 0, 0 };
+    orc_scene_set_envmap(&s, rgb, w, h, RTX_ENV_SPHERICAL, 180.f, bg);
+    for (size_t i = 0; i < s.envBins.size() && int(i) < cap; i++) {
+        out[4 * i + 0] = s.envBins[i].lx, out[4 * i + 1] = s.envBins[i].ly;
+        out[4 * i + 2] = s.envBins[i].ux, out[4 * i + 3] = s.envBins[i].uy;
+    }
+    return int(s.envBins.size());
+}
+// sample2D of a rectangle with the engine seeded from draw `index` of (seed, pixel, sample 0)
+void orc_kat_sample2d(const float* rect, int h, int k, uint32_t seed, uint32_t pixel, uint32_t index, float* out)
+{
+    std::vector<float> v;
+    sample2D(Scene::Rect { rect[0], rect[1], rect[2], rect[3] }, h, k, sampleKey(seed, pixel, 0), index, v);
+    std::copy(v.begin(), v.end(), out);
+}
+// EnvironmentMap::getSamplingRay for (seed, pixel), counter from 0; returns the number of rays (<= cap written)
+int orc_kat_env_rays(const float* rgb, int w, int h, int mapping, float vfovDegrees, const float* position, const float* normal, int n,
+    uint32_t seed, uint32_t pixel, rtx_ray* out, int cap)
+{
+    Scene s;
+    const float bg[3] = { 0, 0, 0 };
+    orc_scene_set_envmap(&s, rgb, w, h, mapping, vfovDegrees, bg);
+    Ctx cx { s, Feat {}, n, 1, PixelRng {}, Counters {} };
+    cx.rng.seed = seed;
+    cx.rng.start(pixel, 0);
+    std::vector<Ray> rays;
+    envSamplingRays(cx, mk(position), mk(normal), n, rays);
+    for (size_t i = 0; i < rays.size() && int(i) < cap; i++) {
+        put(out[i].origin, rays[i].o);
+        put(out[i].direction, rays[i].d);
+        out[i].t = rays[i].t;
+    }
+    return int(rays.size());
 }
 void orc_kat_light_samples(const rtx_light* l, uint32_t seed, uint32_t pixel, int n, float* pos, float* col)
 {

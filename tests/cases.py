@@ -59,8 +59,18 @@ class Case:
         return scene, f, cam, rp
 
 
+def sun_image(seed=5, w=96, h=48):
+    """Environment image with a dim sky and one bright patch, so that the radiance
+    bins of the importance sampler (src/environment_mapping.cpp:55-105) differ in size."""
+    rng = np.random.default_rng(seed)
+    a = np.floor(rng.random((h, w, 3)) * 40) / 255.0
+    a[h // 6:h // 3, w // 2:w // 2 + w // 6] = 1.0
+    return a.astype(np.float32)
+
+
 W = 64
 _ENV = env_image()
+_SUN = sun_image()
 _AREA = [abi.parallelogram_light((-0.2, 0.5, 0.0), (0.4, 0, 0), (0, 0, 0.4), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1))]
 
 IMAGE_CASES = [
@@ -98,6 +108,15 @@ IMAGE_CASES = [
     Case("monkey_env_spherical", "monkey", dict(BASE, environment_mapping=1), dict(width=W, height=W), env=(_ENV, abi.ENV_SPHERICAL, 180.0, (0.5, 0.5, 0.5))),
     Case("monkey_env_cylindrical_bilinear", "monkey", dict(BASE, environment_mapping=1, bilinear_texture_filtering=1, recursive=1), dict(width=W, height=W),
          env=(_ENV, abi.ENV_CYLINDRICAL, 120.0, (0.5, 0.5, 0.5))),
+    # environment light importance sampling (src/light.cpp:47-66): soft shadows + environment map
+    Case("monkey_envlight_spherical", "monkey", dict(BASE, soft_shadow=1, environment_mapping=1), dict(width=40, height=40, shadow_samples=12),
+         ref_mode=1, env=(_SUN, abi.ENV_SPHERICAL, 180.0, (0.2, 0.2, 0.2))),
+    Case("cornell_envlight_cyl_unshadowed", "cornell", dict(BASE, hard_shadow=0, soft_shadow=1, environment_mapping=1, bilinear_texture_filtering=1, recursive=1, glossy_reflection=1),
+         dict(width=32, height=32, shadow_samples=50, glossy_rays=2, ray_depth=1), ref_mode=1, env=(_SUN, abi.ENV_CYLINDRICAL, 120.0, (0.1, 0.2, 0.3))),
+    Case("monkey_envlight_constant", "monkey", dict(BASE, soft_shadow=1, environment_mapping=1), dict(width=40, height=40, shadow_samples=5),
+         ref_mode=1, env=(None, abi.ENV_SPHERICAL, 180.0, (0.6, 0.5, 0.4))),
+    Case("teapot_envlight_area_mrays", "teapot", dict(BASE, soft_shadow=1, environment_mapping=1), dict(width=24, height=24, driver=abi.DRIVER_MRAYS, samples=3, shadow_samples=100),
+         ref_mode=1, env=(_SUN, abi.ENV_SPHERICAL, 90.0, (0.0, 0.0, 0.0)), lights=_AREA + [abi.point_light((1.0, 1.0, -1.0), (0.4, 0.4, 0.4))]),
 ]
 
 CASES_BY_NAME = {c.name: c for c in IMAGE_CASES}

@@ -257,6 +257,24 @@ def make_kat():
     out["minstd_0"] = E.kat_minstd(0, 64)
     out["minstd_100000"] = E.kat_minstd(100000, 64)
     out["minstd_range"] = E.kat_minstd(7, 64, -0.05, 0.05)
+    # environment light importance sampling: radiance bins, multi-jittered samples
+    # (std::shuffle of this container's libstdc++ on the keyed engine), sampling rays
+    sun = cases.sun_image()
+    out["envlight_image"] = sun
+    out["envlight_bins_sun"] = E.kat_env_bins(sun)
+    out["envlight_bins_noise"] = E.kat_env_bins(env)
+    rects = rng.uniform(0, 0.5, (12, 4)).astype(f32)
+    rects[:, 2:] += 0.5
+    out["sample2d_rects"] = rects
+    for hk in (1, 2, 3, 5, 8):
+        out[f"sample2d_{hk}"] = np.stack([E.kat_sample2d(rects[i], hk, hk, 11, i, 2 * i + 1) for i in range(len(rects))])
+    pos = rng.uniform(-1, 1, (6, 3)).astype(f32)
+    nrm = rng.normal(size=(6, 3)).astype(f32)
+    out["envrays_pos"], out["envrays_nrm"] = pos, nrm
+    for tag, mapping, vfov in (("sph180", abi.ENV_SPHERICAL, 180.0), ("cyl100", abi.ENV_CYLINDRICAL, 100.0)):
+        for n in (1, 9, 50, 100):
+            for i in range(len(pos)):
+                out[f"envrays_{tag}_{n}_{i}"] = E.kat_env_rays(sun, mapping, vfov, pos[i], nrm[i], n, 5, i)
     np.savez_compressed(os.path.join(OUT, "kat.npz"), **out)
     print("kat", len(out), "arrays")
 

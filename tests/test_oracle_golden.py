@@ -101,6 +101,28 @@ def test_samplers_and_rng_streams(golden_kat):
     assert same(E.kat_minstd(7, 64, -0.05, 0.05), g["minstd_range"])
 
 
+def test_environment_light_sampling(golden_kat):
+    """Radiance bins, sample2D (std::shuffle + uniform_real on one keyed engine) and
+    EnvironmentMap::getSamplingRay against the reference's outputs."""
+    g = golden_kat
+    sun = g["envlight_image"]
+    assert same(E.kat_env_bins(sun), g["envlight_bins_sun"])
+    assert same(E.kat_env_bins(g["env_image"]), g["envlight_bins_noise"])
+    assert len(g["envlight_bins_sun"]) > 1
+    rects = g["sample2d_rects"]
+    for hk in (1, 2, 3, 5, 8):
+        for i in range(len(rects)):
+            got = E.kat_sample2d(rects[i], hk, hk, 11, i, 2 * i + 1)
+            assert same(got, g[f"sample2d_{hk}"][i]), (hk, i)
+    for tag, mapping, vfov in (("sph180", abi.ENV_SPHERICAL, 180.0), ("cyl100", abi.ENV_CYLINDRICAL, 100.0)):
+        for n in (1, 9, 50, 100):
+            for i in range(len(g["envrays_pos"])):
+                got = E.kat_env_rays(sun, mapping, vfov, g["envrays_pos"][i], g["envrays_nrm"][i], n, 5, i)
+                want = g[f"envrays_{tag}_{n}_{i}"]
+                assert len(got) == len(want)
+                assert same(got["origin"], want["origin"]) and same(got["direction"], want["direction"]), (tag, n, i)
+
+
 def _walk(d):
     sizes, tris, boxes = [], [], []
 

@@ -43,6 +43,11 @@ def main():
     area = [abi.parallelogram_light((-0.2, 0.9, 0.0), (0.4, 0, 0), (0, 0, 0.4), (1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1))]
     variations += [
         ("area light 64 samples", dict(soft_shadow=1, hard_shadow=0), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, ray_depth=0), area),
+        ("area light 16 samples", dict(soft_shadow=1, hard_shadow=0), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=16, ray_depth=0), area),
+        ("area light 32 samples", dict(soft_shadow=1, hard_shadow=0), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=32, ray_depth=0), area),
+        ("area light 128 samples", dict(soft_shadow=1, hard_shadow=0), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=128, ray_depth=0), area),
+        ("area light 64, close-up", dict(soft_shadow=1, hard_shadow=0), dict(distance=1.2), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, ray_depth=0), area),
+        ("general path 1 spp", dict(recursive=1), dict(), dict(driver=abi.DRIVER_PLAIN, ray_depth=0), None),
         ("area 64 + glossy depth 2", dict(soft_shadow=1, hard_shadow=0, recursive=1, glossy_reflection=1), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=2), area),
         ("mirror depth 4", dict(recursive=1), dict(), dict(driver=abi.DRIVER_PLAIN, ray_depth=4), None),
         ("transparency driver", dict(), dict(), dict(driver=abi.DRIVER_TRANSPARENCY), None),
