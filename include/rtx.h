@@ -167,6 +167,11 @@ typedef struct rtx_scene_desc {
     rtx_envmap          envmap;
     int32_t             num_levels;  /* BvhInterface::numLevels                 */
     int32_t             num_leaves;  /* BvhInterface::numLeaves                 */
+    /* EnvironmentMap::radianceBins (src/environment_mapping.cpp:42-105): rectangles of the
+     * environment image as (lower.x, lower.y, upper.x, upper.y), built on the host; the
+     * device draws its environment-light samples from them (src/light.cpp:47-66).
+     * May be empty: a constant-colour environment has none. */
+    const float*        env_bins;    uint32_t n_env_bins;
 } rtx_scene_desc;
 
 /* ---- camera: Trackball state (framework/src/trackball.cpp:64-110) --------- */

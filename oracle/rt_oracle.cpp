@@ -1027,7 +1027,9 @@ V3 lightContribution(Ctx& cx, const Ray& ray, const Hit& hit)
             }
         }
     }
-    if (cx.f.softShadow && cx.f.envMap && s.hasEnv)
+    // (a scene without an environment map behaves like the reference's default
+    // EnvironmentMap(glm::vec3 {0}): one ray along the normal, black)
+    if (cx.f.softShadow && cx.f.envMap)
         med = med + sampleEnvironment(cx, ray, hit);
     return med;
 }

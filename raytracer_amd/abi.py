@@ -71,7 +71,8 @@ class SceneDesc(C.Structure):
                 ("texels", C.c_void_p), ("n_texels", C.c_uint64),
                 ("lights", C.c_void_p), ("n_lights", u32),
                 ("spheres", C.c_void_p), ("n_spheres", u32),
-                ("envmap", EnvMap), ("num_levels", i32), ("num_leaves", i32)]
+                ("envmap", EnvMap), ("num_levels", i32), ("num_leaves", i32),
+                ("env_bins", C.c_void_p), ("n_env_bins", u32)]
 
 
 RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("t", "<f4")])

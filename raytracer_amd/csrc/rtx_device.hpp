@@ -56,6 +56,8 @@ struct DScene {
     const rtx_light* lights;
     const rtx_sphere* spheres;
     rtx_envmap env;
+    const float4* envBins;   // radiance bins of the environment image: (lower.x, lower.y, upper.x, upper.y)
+    int32_t nEnvBins;
     int32_t nTris, nLights, nSpheres, nMaterials;
     int32_t rootRef;
     float rootLo[3], rootHi[3];
@@ -640,6 +642,122 @@ RTX_DEV float keyedUniform(uint32_t key, uint32_t counter)
     if (u >= 1.0f)
         u = 0.99999994f;
     return u;
+}
+
+// ------------------------------------------ environment light sampling ----
+// The reference's sample2D (src/sampling.cpp:6-60) seeds ONE engine from a
+// random_device draw and then runs std::shuffle and uniform_real_distribution on
+// it.  With the keyed stream standing in for random_device, output m of the
+// engine made from draw `index` is bits(index) for m = 0 and
+// mix32(bits(index) + m + 1) after that; the shuffle and the integer
+// distribution below are libstdc++'s (bits/stl_algo.h, bits/uniform_int_dist.h:
+// two swap positions per engine call, Lemire's nearly divisionless reduction).
+constexpr int kEnvMaxPerTry = 8; // side of the largest multi-jitter grid handled (light samples < 810)
+
+struct DrawEngine {
+    uint32_t base, m;
+};
+RTX_DEV DrawEngine engineAt(uint32_t key, uint32_t index)
+{
+    return DrawEngine { mix32(key ^ (index * 0x85ebca77u) ^ 0x68bc21ebu), 0u };
+}
+RTX_DEV uint32_t engineNext(DrawEngine& g)
+{
+    const uint32_t v = g.m == 0 ? g.base : mix32(g.base + g.m + 1u);
+    g.m++;
+    return v;
+}
+RTX_DEV uint32_t uniformBelow(DrawEngine& g, uint32_t range)
+{
+    uint64_t product = uint64_t(engineNext(g)) * uint64_t(range);
+    uint32_t low = uint32_t(product);
+    if (low < range) {
+        const uint32_t threshold = (0u - range) % range;
+        while (low < threshold) {
+            product = uint64_t(engineNext(g)) * uint64_t(range);
+            low = uint32_t(product);
+        }
+    }
+    return uint32_t(product >> 32);
+}
+// std::shuffle of a[first .. first + n)
+RTX_DEV void shuffleBytes(uint8_t* a, int first, uint32_t n, DrawEngine& g)
+{
+    if (n == 0)
+        return;
+    uint32_t i = 1;
+    if (n % 2 == 0) {
+        const uint32_t p = uniformBelow(g, 2);
+        const uint8_t t = a[first + i];
+        a[first + i] = a[first + p];
+        a[first + p] = t;
+        i++;
+    }
+    while (i != n) {
+        const uint32_t swapRange = i + 1;
+        const uint32_t x = uniformBelow(g, swapRange * (swapRange + 1));
+        const uint32_t p0 = x / (swapRange + 1), p1 = x % (swapRange + 1);
+        uint8_t t = a[first + i];
+        a[first + i] = a[first + p0];
+        a[first + p0] = t;
+        i++;
+        t = a[first + i];
+        a[first + i] = a[first + p1];
+        a[first + p1] = t;
+        i++;
+    }
+}
+// Sample number c (row-major: c = j * h + i) of sample2D(rect, h, h) whose engine is
+// seeded from draw `index`: the shuffles are replayed, then the engine is moved to
+// this sample's two jitter draws.
+__device__ __attribute__((noinline)) void sample2DAt(float4 rect, int h, uint32_t key, uint32_t index, int c, float& sx, float& sy)
+{
+    DrawEngine g = engineAt(key, index);
+    uint8_t cell[kEnvMaxPerTry * kEnvMaxPerTry]; // rows[j][i] = (j, i), packed j * 16 + i
+    uint8_t order[kEnvMaxPerTry];
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < h; i++)
+            cell[j * h + i] = uint8_t(j * 16 + i);
+    for (int i = 0; i < h; i++)
+        order[i] = uint8_t(i);
+    for (int j = 0; j < h; j++)
+        shuffleBytes(cell, j * h, uint32_t(h), g);
+    for (int i = 0; i < h; i++) {
+        shuffleBytes(order, 0, uint32_t(h), g);
+        int j = 0;
+        const uint8_t temp = cell[i];
+        for (int x = 0; x < h; x++) {
+            cell[j * h + i] = cell[int(order[x]) * h + i];
+            j = order[x];
+        }
+        cell[j * h + i] = temp;
+    }
+    g.m += 2u * uint32_t(c);
+    const int j = c / h, i = c - j * h;
+    const float centerX = float(cell[c] >> 4), centerY = float(cell[c] & 15);
+    float jx = float(engineNext(g)) * 2.3283064365386963e-10f;
+    if (jx >= 1.0f)
+        jx = 0.99999994f;
+    float jy = float(engineNext(g)) * 2.3283064365386963e-10f;
+    if (jy >= 1.0f)
+        jy = 0.99999994f;
+    const float scale = float(1. / double(h + 1));
+    const float subX = centerX + jx, subY = centerY + jy;
+    sx = rect.x + (rect.z - rect.x) * (float(double(i) / (double(h) + 1.)) + scale * subX);
+    sy = rect.y + (rect.w - rect.y) * (float(double(j) / (double(h) + 1.)) + scale * subY);
+}
+// EnvironmentMap::getRayForCoordinate, src/environment_mapping.cpp:130-165
+RTX_DEV V3 envDirection(const DScene& sc, float cx, float cy)
+{
+    const double kPi = 3.14159265358979323846;
+    const float azimuth = float(2.0 * kPi * (double(cx) - 0.5));
+    float pitch;
+    if (sc.env.mapping == RTX_ENV_SPHERICAL)
+        pitch = float((0.5 - double(cy)) * double(sc.env.vfov_radians));
+    else
+        pitch = float(atan(double(tanf(0.5f * sc.env.vfov_radians)) * (0.5 - double(cy)) / 0.5));
+    const float px = cosf(pitch), py = sinf(pitch);
+    return mk(px * cosf(azimuth), py, px * sinf(azimuth));
 }
 
 // std::default_random_engine (minstd_rand0: x <- 16807 x mod 2^31-1, seed 1) as

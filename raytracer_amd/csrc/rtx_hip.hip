@@ -33,7 +33,7 @@ namespace {
 #define RTX_LEAN_WAVES 4
 #endif
 #ifndef RTX_FULL_WAVES
-#define RTX_FULL_WAVES 1
+#define RTX_FULL_WAVES 2
 #endif
 constexpr int kMaxDepth = 8;    // frames of the reflection recursion kept per lane
 constexpr int kMaxLayers = 16;  // transparent layers along one camera ray
@@ -278,8 +278,8 @@ struct Frame { // one suspended getFinalColor call (src/render.cpp:16-66)
     uint32_t rngBase;
 };
 
-enum PathState { PS_DONE = 0, PS_RADIANCE = 1, PS_SHADOW = 2, PS_AREA = 3 };
-enum Phase { PH_NONE = -1, PH_NEXT_LIGHT, PH_AFTER_LIGHTS, PH_NEXT_CHILD, PH_RETURN };
+enum PathState { PS_DONE = 0, PS_RADIANCE = 1, PS_SHADOW = 2, PS_AREA = 3, PS_ENV = 4 };
+enum Phase { PH_NONE = -1, PH_NEXT_LIGHT, PH_ENV, PH_AFTER_LIGHTS, PH_NEXT_CHILD, PH_RETURN };
 
 RTX_DEV float laneValue(float v, int srcLane) { return __shfl(v, srcLane, 64); }
 RTX_DEV V3 laneValue(V3 v, int srcLane) { return mk(__shfl(v.x, srcLane, 64), __shfl(v.y, srcLane, 64), __shfl(v.z, srcLane, 64)); }
@@ -342,6 +342,13 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     const int mySlot = lane / group, mySample = lane - mySlot * group;
     int areaRound = 0;
     V3 areaCarry = mk(0, 0, 0);
+
+    // environment light (sampleEnvironment, src/light.cpp:47-66): which try and which
+    // sample of the try comes next, how many rays were kept, the sum so far
+    const bool envLight = FULL && f.enable_soft_shadow && f.enable_environment_mapping;
+    const int envPerTry = int(fmax(sqrt(double(nS) / 10.), 1.)); // src/environment_mapping.cpp:110
+    int envTry = 0, envCand = 0, envCount = 0;
+    V3 envAvg = mk(0, 0, 0);
 
     bool shadedPending = false; // counted at the loop head, where the wave is converged
     bool firstQuery = true;
@@ -411,14 +418,16 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
         } else {
             if (firstQuery)
                 t = firstLimit;
-            lc.countShadow(state == PS_SHADOW);
+            lc.countShadow(state == PS_SHADOW || state == PS_ENV);
             lc.countPrimary(state == PS_RADIANCE && level == 0);
             lc.countBounce(state == PS_RADIANCE && level != 0);
-            trace = state == PS_RADIANCE || (state == PS_SHADOW && !shadowBehind);
+            trace = state == PS_RADIANCE || state == PS_ENV || (state == PS_SHADOW && !shadowBehind);
             if (state == PS_SHADOW) {
                 qStop = shadowStop;
                 qLimit = shadowLimit;
             }
+            if (state == PS_ENV)
+                qStop = kFltMax; // only "hit anything?" matters: stop at the first hit (t drops below its initial kFltMax)
             firstQuery = false;
         }
 
@@ -484,6 +493,13 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
             Lo = Lo + sh * vis;
             li++;
             phase = PH_NEXT_LIGHT;
+        } else if (FULL && state == PS_ENV) {
+            // src/light.cpp:56-59: an unblocked ray brings the map's colour from far away
+            if (!any) {
+                const V3 envN = dot(hitN, Rd) < 0 ? hitN : -hitN;
+                envAvg = envAvg + phong(ro + 100000.f * rd, envColor(sc, f, rd), hp, Rd, envN, albedo, ks, shin);
+            }
+            phase = PH_ENV;
         } else if (state == PS_RADIANCE) {
             // result of a radiance ray = body of getFinalColor
             if (transparencyDriver && level == 0) {
@@ -525,7 +541,7 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
         while (!launched) {
             if (phase == PH_NEXT_LIGHT) {
                 // computeLightContribution, src/light.cpp:139-189
-                phase = PH_AFTER_LIGHTS;
+                phase = envLight ? PH_ENV : PH_AFTER_LIGHTS;
                 while (li < sc.nLights) {
                     const rtx_light& L = sc.lights[li];
                     if (L.type == RTX_LIGHT_POINT) {
@@ -554,6 +570,62 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                         break;
                     }
                     li++; // segment / parallelogram lights only count with soft shadows (src/light.cpp:154,167)
+                }
+                if (launched)
+                    break;
+                // all lights done: the environment light, if any, starts from scratch
+                envTry = envCand = envCount = 0;
+                envAvg = mk(0, 0, 0);
+            }
+            if (FULL && phase == PH_ENV) {
+                // sampleEnvironment + EnvironmentMap::getSamplingRay (src/light.cpp:47-66,
+                // src/environment_mapping.cpp:107-128): up to 100 tries, each a random radiance
+                // bin sampled on a small multi-jittered grid; rays leaving the surface are kept
+                // until there are at least shadowSamples of them.  Two keyed draws per try:
+                // the bin, then the seed of the grid's engine.
+                const V3 envN = dot(hitN, Rd) < 0 ? hitN : -hitN;
+                for (;;) {
+                    V3 dir = envN, org = hp;
+                    bool have = false, finished = false;
+                    if (sc.env.texture < 0) {
+                        // constant-colour environment: one ray along the normal
+                        finished = envTry != 0;
+                        have = !finished;
+                        envTry = 1;
+                    } else if (envCand == 0 && !(envCount < nS && envTry < 100)) {
+                        finished = true;
+                        counter += 2u * uint32_t(envTry);
+                    } else {
+                        const float binDraw = keyedUniform(rngKey, counter + 2u * uint32_t(envTry));
+                        const int bin = min(int(floorf(binDraw * float(sc.nEnvBins))), sc.nEnvBins - 1);
+                        float sx, sy;
+                        sample2DAt(sc.envBins[bin], envPerTry, rngKey, counter + 2u * uint32_t(envTry) + 1u, envCand, sx, sy);
+                        dir = envDirection(sc, sx, sy);
+                        const float eps = 0.0001f / dot(normalize(dir), envN);
+                        org = hp + eps * dir;
+                        have = dot(dir, envN) > 0.f;
+                        if (++envCand == envPerTry * envPerTry) {
+                            envCand = 0;
+                            envTry++;
+                        }
+                        if (have)
+                            envCount++;
+                    }
+                    if (finished) {
+                        Lo = Lo + envAvg * float(1.0 / double(float(nS)));
+                        phase = PH_AFTER_LIGHTS;
+                        break;
+                    }
+                    if (!have)
+                        continue;
+                    if (f.enable_hard_shadow) {
+                        ro = org;
+                        rd = dir;
+                        state = PS_ENV;
+                        launched = true;
+                        break;
+                    }
+                    envAvg = envAvg + phong(org + 100000.f * dir, envColor(sc, f, dir), hp, Rd, envN, albedo, ks, shin);
                 }
                 if (launched)
                     break;
@@ -983,7 +1055,7 @@ struct rtx_scene {
     int device = -1;
     int refs = 1;
     DScene d {};
-    void* buffers[10] = {};
+    void* buffers[12] = {};
     int nBuffers = 0;
     int numLevels = 0;
     bool hasEnv = false;
@@ -1203,6 +1275,23 @@ int tileGeom(const rtx_render_params* p, TileGeom& g)
     return RTX_OK;
 }
 
+// Environment-light sampling (soft shadows + environment mapping) needs the radiance
+// bins of a textured environment and a multi-jitter grid the kernel can hold.
+int checkEnvLight(const rtx_scene* scene, const rtx_features* f, int shadowSamples)
+{
+    if (!(f->enable_soft_shadow && f->enable_environment_mapping))
+        return RTX_OK;
+    if (scene->d.env.texture >= 0 && scene->d.nEnvBins <= 0) {
+        setErr("environment light sampling needs rtx_scene_desc.env_bins for a textured environment map");
+        return RTX_ERR_INVALID;
+    }
+    if (int(std::sqrt(double(shadowSamples) / 10.)) > kEnvMaxPerTry) {
+        setErr("shadow_samples %d: environment light sampling handles fewer than %d", shadowSamples, 10 * (kEnvMaxPerTry + 1) * (kEnvMaxPerTry + 1));
+        return RTX_ERR_LIMIT;
+    }
+    return RTX_OK;
+}
+
 int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dOut, bool compact, rtx_stats* stats, double t0)
 {
     DeviceCtx* c = g_ctx;
@@ -1236,6 +1325,8 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     }
     A.samples = !sampled ? 1 : (p->samples > 0 ? p->samples : (driver == RTX_DRIVER_MRAYS ? 64 : driver == RTX_DRIVER_DOF ? 100 : 7));
     A.shadowSamples = p->shadow_samples > 0 ? p->shadow_samples : 50;
+    if (int rc = checkEnvLight(scene, f, A.shadowSamples))
+        return rc;
     A.glossyRays = p->glossy_rays > 0 ? p->glossy_rays : 5;
     A.seed = p->seed;
     A.aperture = p->aperture > 0.f ? p->aperture : 0.1f;
@@ -1354,6 +1445,8 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
     }
     A.samples = 1;
     A.shadowSamples = p->shadow_samples > 0 ? p->shadow_samples : 50;
+    if (int rc = checkEnvLight(scene, f, A.shadowSamples))
+        return rc;
     A.glossyRays = p->glossy_rays > 0 ? p->glossy_rays : 5;
     A.seed = p->seed;
     A.work.nUnits = uint32_t((n + 63) / 64);
@@ -1489,6 +1582,10 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
                 return nullptr;
             }
     }
+    if (d->n_env_bins && !d->env_bins) {
+        setErr("rtx_scene_create: %u environment bins but NULL array", d->n_env_bins);
+        return nullptr;
+    }
     for (uint32_t i = 0; i < d->n_lights; i++)
         if (d->lights[i].type < RTX_LIGHT_POINT || d->lights[i].type > RTX_LIGHT_PARALLELOGRAM) {
             setErr("rtx_scene_create: light %u has unknown type %d", i, d->lights[i].type);
@@ -1517,6 +1614,9 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     rc = rc ? rc : upload(s, d->texels, size_t(d->n_texels) * 3, &s->d.texels);
     rc = rc ? rc : upload(s, d->lights, d->n_lights, &s->d.lights);
     rc = rc ? rc : upload(s, d->spheres, d->n_spheres, &s->d.spheres);
+    const float* bins = nullptr;
+    rc = rc ? rc : upload(s, d->env_bins, size_t(d->n_env_bins) * 4, &bins);
+    s->d.envBins = reinterpret_cast<const float4*>(bins);
     if (rc) {
         rtx_scene_destroy(s);
         return nullptr;
@@ -1527,6 +1627,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     s->d.env = d->envmap;
     s->d.nTris = int32_t(d->n_tris);
     s->d.nLights = int32_t(d->n_lights);
+    s->d.nEnvBins = int32_t(d->n_env_bins);
     for (uint32_t i = 0; i < d->n_lights; i++)
         s->hasAreaLight = s->hasAreaLight || d->lights[i].type != RTX_LIGHT_POINT;
     s->d.nSpheres = int32_t(d->n_spheres);

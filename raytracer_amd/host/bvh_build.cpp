@@ -190,6 +190,46 @@ rtx_material toMaterial(FlatScene& out, const Material& m, std::map<const Image*
     return r;
 }
 
+// Radiance bins of the environment image: EnvironmentMap's constructor and
+// buildRadianceHierarchy (src/environment_mapping.cpp:26-29,42-105).  The image is
+// halved along its longer side again and again, each time following the half (or
+// halves) holding more than half of the radiance, until a piece is dim or small;
+// every piece left over is a bin.  Arithmetic as in the reference: radiance in
+// double rounded to float, sums in float, pixel ranges by float-to-int truncation.
+float radianceOf(const vec3& c) { return float(0.25 * (double(c.x) + 2. * double(c.y) + double(c.z))); }
+
+void radianceBins(const Image& img, float lx, float ly, float ux, float uy, float totalRadiance, std::vector<float>& out)
+{
+    auto keep = [&](float a, float b, float c, float d) {
+        out.push_back(a), out.push_back(b), out.push_back(c), out.push_back(d);
+    };
+    const float sizeX = ux - lx, sizeY = uy - ly;
+    const float minRadiance = float((img.width * img.height) / 1000);
+    if (totalRadiance < minRadiance || double(sizeX + sizeY) < 0.1) {
+        keep(lx, ly, ux, uy);
+        return;
+    }
+    const float imageW = float(img.width), m1x = float(img.width - 1), m1y = float(img.height - 1);
+    const bool splitVertically = sizeY / sizeX > 1.f;
+    const float splitX = splitVertically ? ux : float(0.5 * double(lx + ux));
+    const float splitY = splitVertically ? float(0.5 * double(ly + uy)) : uy;
+    const float fromX = lx * m1x, fromY = ly * m1y, toX = splitX * m1x, toY = splitY * m1y;
+    float lowerHalf = 0.f;
+    for (int i = int(fromX); float(i) < toX; i++)
+        for (int j = int(fromY); float(j) < toY; j++)
+            lowerHalf += radianceOf(img.pixels[size_t(float(i) + float(j) * imageW)]);
+    const float upperHalf = totalRadiance - lowerHalf;
+    if (double(lowerHalf) > 0.5 * double(totalRadiance))
+        radianceBins(img, lx, ly, splitX, splitY, lowerHalf, out);
+    else
+        keep(lx, ly, splitX, splitY);
+    const float l2x = splitVertically ? lx : splitX, l2y = splitVertically ? splitY : ly;
+    if (double(upperHalf) > 0.5 * double(totalRadiance))
+        radianceBins(img, l2x, l2y, ux, uy, upperHalf, out);
+    else
+        keep(l2x, l2y, ux, uy);
+}
+
 } // namespace
 
 FlatScene flattenScene(const Scene& scene, const Features& features)
@@ -243,6 +283,12 @@ FlatScene flattenScene(const Scene& scene, const Features& features)
         out.envmap.mapping = e.mappingType == SPHERICAL ? RTX_ENV_SPHERICAL : RTX_ENV_CYLINDRICAL;
         out.envmap.vfov_radians = radians(e.verticalFieldOfViewDegrees);
         std::memcpy(out.envmap.background, &e.backgroundColor, 12);
+        if (e.texture && e.texture->pixels.size() >= size_t(e.texture->width) * size_t(e.texture->height) && !e.texture->pixels.empty()) {
+            float total = 0.f;
+            for (const vec3& px : e.texture->pixels)
+                total += radianceOf(px);
+            radianceBins(*e.texture, 0.f, 0.f, 1.f, 1.f, total, out.envBins);
+        }
     }
 
     // meshTrianglePairs in mesh-major order, src/bounding_volume_hierarchy.cpp:166-175
@@ -313,6 +359,8 @@ rtx_scene_desc FlatScene::desc() const
     d.envmap = envmap;
     d.num_levels = numLevels;
     d.num_leaves = numLeaves;
+    d.env_bins = envBins.data();
+    d.n_env_bins = uint32_t(envBins.size() / 4);
     return d;
 }
 

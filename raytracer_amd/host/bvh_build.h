@@ -23,6 +23,7 @@ struct FlatScene {
     std::vector<rtx_light> lights;
     std::vector<rtx_sphere> spheres;
     rtx_envmap envmap { -1, RTX_ENV_SPHERICAL, 1.f, { 0, 0, 0 } };
+    std::vector<float> envBins;         // radiance bins of the environment image, 4 floats each
     int32_t rootRef = INT32_MIN, rootCnt = 0;
     float rootLo[3] = { 0, 0, 0 }, rootHi[3] = { 0, 0, 0 };
     int numLevels = 0, numLeaves = 0;

@@ -85,6 +85,26 @@ def test_textures_are_flattened_with_their_mip_chains(golden_kat):
     flat.close()
 
 
+def test_environment_radiance_bins_are_the_reference_bins(golden_kat):
+    """EnvironmentMap's constructor + buildRadianceHierarchy (src/environment_mapping.cpp:42-105),
+    restated in the host flattener, against the bins the reference built."""
+    for image, key in ((golden_kat["envlight_image"], "envlight_bins_sun"), (golden_kat["env_image"], "envlight_bins_noise")):
+        scene = cases.load_scene("triangle")
+        scene.set_envmap(image, abi.ENV_SPHERICAL, 180.0, (0, 0, 0))
+        fl = engine.flatten(scene, abi.features(accel_structure=1))
+        d = fl.desc()
+        bins = np.ctypeslib.as_array(C.cast(d.env_bins, C.POINTER(C.c_float)), shape=(d.n_env_bins, 4)).copy()
+        fl.close()
+        assert bins.shape == golden_kat[key].shape
+        assert np.array_equal(bins.view(np.uint32), golden_kat[key].view(np.uint32))
+    # a constant-colour environment has no bins
+    scene = cases.load_scene("triangle")
+    scene.set_envmap(None, abi.ENV_SPHERICAL, 180.0, (0.5, 0.5, 0.5))
+    fl = engine.flatten(scene, abi.features(accel_structure=1))
+    assert fl.desc().n_env_bins == 0
+    fl.close()
+
+
 def test_empty_scene_and_single_triangle():
     s = SceneData()
     flat = engine.flatten(s, abi.features(accel_structure=1))
