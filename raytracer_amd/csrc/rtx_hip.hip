@@ -298,7 +298,7 @@ RTX_DEV V3 laneValue(V3 v, int srcLane) { return mk(__shfl(v.x, srcLane, 64), __
 // contributions are added up in sample order along the lanes and handed back.
 // A path's long sequential run of shadow samples thus becomes one traversal step
 // of a full wave, however few lanes of the wave have a shading point.
-template <int STACK, bool COUNT, bool FULL>
+template <int STACK, bool COUNT, bool FULL, bool ENVL = false>
 RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD, bool active, uint32_t rngKey, LaneCounters& lc, float firstLimit = kFltMax)
 {
     const DScene& sc = A.sc;
@@ -345,7 +345,8 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
 
     // environment light (sampleEnvironment, src/light.cpp:47-66): which try and which
     // sample of the try comes next, how many rays were kept, the sum so far
-    const bool envLight = FULL && f.enable_soft_shadow && f.enable_environment_mapping;
+    // (compiled in only for ENVL: its code costs the other paths registers)
+    const bool envLight = FULL && ENVL && f.enable_soft_shadow && f.enable_environment_mapping;
     const int envPerTry = int(fmax(sqrt(double(nS) / 10.), 1.)); // src/environment_mapping.cpp:110
     int envTry = 0, envCand = 0, envCount = 0;
     V3 envAvg = mk(0, 0, 0);
@@ -493,7 +494,7 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
             Lo = Lo + sh * vis;
             li++;
             phase = PH_NEXT_LIGHT;
-        } else if (FULL && state == PS_ENV) {
+        } else if (FULL && ENVL && state == PS_ENV) {
             // src/light.cpp:56-59: an unblocked ray brings the map's colour from far away
             if (!any) {
                 const V3 envN = dot(hitN, Rd) < 0 ? hitN : -hitN;
@@ -577,7 +578,7 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                 envTry = envCand = envCount = 0;
                 envAvg = mk(0, 0, 0);
             }
-            if (FULL && phase == PH_ENV) {
+            if (FULL && ENVL && phase == PH_ENV) {
                 // sampleEnvironment + EnvironmentMap::getSamplingRay (src/light.cpp:47-66,
                 // src/environment_mapping.cpp:107-128): up to 100 tries, each a random radiance
                 // bin sampled on a small multi-jittered grid; rays leaving the surface are kept
@@ -787,9 +788,12 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
     return result;
 }
 
-template <int STACK, bool COUNT, bool FULL>
-__global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES) renderKernel(RenderArgs A)
+// MODE 0: point lights + hard shadows only (tracePathLean); 1: the general path;
+// 2: the general path with environment light sampling
+template <int STACK, bool COUNT, int MODE>
+__global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES) renderKernel(RenderArgs A)
 {
+    constexpr bool FULL = MODE != 0;
     __shared__ int32_t sRefs[STACK * kBlock];
     __shared__ float sKeys[STACK * kBlock];
     LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
@@ -874,7 +878,7 @@ __global__ void __launch_bounds__(kBlock, FULL ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                     }
                 }
             }
-            const V3 c = FULL ? tracePath<STACK, COUNT, true>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT>(A, st, o, d, active, lc);
+            const V3 c = FULL ? tracePath<STACK, COUNT, true, MODE == 2>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
             } else {
@@ -946,7 +950,7 @@ struct ShadeArgs {
     uint64_t n;
 };
 
-template <int STACK, bool COUNT>
+template <int STACK, bool COUNT, bool ENVL>
 __global__ void __launch_bounds__(kBlock, RTX_FULL_WAVES) shadeKernel(ShadeArgs S)
 {
     __shared__ int32_t sRefs[STACK * kBlock];
@@ -970,7 +974,7 @@ __global__ void __launch_bounds__(kBlock, RTX_FULL_WAVES) shadeKernel(ShadeArgs 
                 d = mk(r.direction);
                 limit = r.t;
             }
-            const V3 c = tracePath<STACK, COUNT, true>(A, st, o, d, active, sampleKey(A.seed, uint32_t(i), 0u), lc, limit);
+            const V3 c = tracePath<STACK, COUNT, true, ENVL>(A, st, o, d, active, sampleKey(A.seed, uint32_t(i), 0u), lc, limit);
             if (active) {
                 S.out[i * 3 + 0] = c.x;
                 S.out[i * 3 + 1] = c.y;
@@ -1134,22 +1138,29 @@ int launchTrace(DeviceCtx* c, const TraceArgs& A, bool count)
 }
 
 template <int STACK>
-int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, bool full)
+int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode)
 {
-#define RTX_LAUNCH(CNT, FULLV)                                                                                     \
-    {                                                                                                              \
-        const void* k = (const void*)renderKernel<STACK, CNT, FULLV>;                                              \
-        const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.work.nChunks + 3) / 4)));                       \
-        hipLaunchKernelGGL((renderKernel<STACK, CNT, FULLV>), dim3(grid), dim3(kBlock), 0, c->stream, A);          \
+#define RTX_LAUNCH(CNT, MODEV)                                                                                    \
+    {                                                                                                             \
+        const void* k = (const void*)renderKernel<STACK, CNT, MODEV>;                                             \
+        const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.work.nChunks + 3) / 4)));                \
+        hipLaunchKernelGGL((renderKernel<STACK, CNT, MODEV>), dim3(grid), dim3(kBlock), 0, c->stream, A);         \
     }
-    if (count && full)
-        RTX_LAUNCH(true, true)
-    else if (count)
-        RTX_LAUNCH(true, false)
-    else if (full)
-        RTX_LAUNCH(false, true)
-    else
-        RTX_LAUNCH(false, false)
+    if (count) {
+        if (mode == 2)
+            RTX_LAUNCH(true, 2)
+        else if (mode == 1)
+            RTX_LAUNCH(true, 1)
+        else
+            RTX_LAUNCH(true, 0)
+    } else {
+        if (mode == 2)
+            RTX_LAUNCH(false, 2)
+        else if (mode == 1)
+            RTX_LAUNCH(false, 1)
+        else
+            RTX_LAUNCH(false, 0)
+    }
 #undef RTX_LAUNCH
     return RTX_OK;
 }
@@ -1361,6 +1372,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // texture / environment machinery; the lean one is enough otherwise
     const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || driver == RTX_DRIVER_TRANSPARENCY
         || driver == RTX_DRIVER_MOTION_BLUR; // per-sample cameras need device trigonometry
+    const int mode = !full ? 0 : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : 1;
 
     // skip-ahead tables for the drivers that draw from the sequential engine
     A.jumpX = c->jump;
@@ -1397,10 +1409,10 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     if (A.work.nUnits) {
         const bool count = wantCounters();
         switch (stack) {
-        case 16: launchRender<16>(c, A, count, full); break;
-        case 24: launchRender<24>(c, A, count, full); break;
-        case 32: launchRender<32>(c, A, count, full); break;
-        default: launchRender<64>(c, A, count, full); break;
+        case 16: launchRender<16>(c, A, count, mode); break;
+        case 24: launchRender<24>(c, A, count, mode); break;
+        case 32: launchRender<32>(c, A, count, mode); break;
+        default: launchRender<64>(c, A, count, mode); break;
         }
         HIP_TRY(hipGetLastError());
     }
@@ -1409,14 +1421,23 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
 }
 
 template <int STACK>
-void launchShade(DeviceCtx* c, const ShadeArgs& S, bool count)
+void launchShade(DeviceCtx* c, const ShadeArgs& S, bool count, bool envLight)
 {
-    const void* k = count ? (const void*)shadeKernel<STACK, true> : (const void*)shadeKernel<STACK, false>;
-    const int grid = std::max(1, std::min<int>(gridFor(c, k), int((S.R.work.nChunks + 3) / 4)));
-    if (count)
-        hipLaunchKernelGGL((shadeKernel<STACK, true>), dim3(grid), dim3(kBlock), 0, c->stream, S);
+#define RTX_LAUNCH(CNT, ENVV)                                                                                  \
+    {                                                                                                          \
+        const void* k = (const void*)shadeKernel<STACK, CNT, ENVV>;                                            \
+        const int grid = std::max(1, std::min<int>(gridFor(c, k), int((S.R.work.nChunks + 3) / 4)));           \
+        hipLaunchKernelGGL((shadeKernel<STACK, CNT, ENVV>), dim3(grid), dim3(kBlock), 0, c->stream, S);        \
+    }
+    if (count && envLight)
+        RTX_LAUNCH(true, true)
+    else if (count)
+        RTX_LAUNCH(true, false)
+    else if (envLight)
+        RTX_LAUNCH(false, true)
     else
-        hipLaunchKernelGGL((shadeKernel<STACK, false>), dim3(grid), dim3(kBlock), 0, c->stream, S);
+        RTX_LAUNCH(false, false)
+#undef RTX_LAUNCH
 }
 
 int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_features* f, const rtx_render_params* p, float* dOut, rtx_stats* stats, double t0)
@@ -1461,10 +1482,10 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
     if (n) {
         const bool count = wantCounters();
         switch (stack) {
-        case 16: launchShade<16>(c, S, count); break;
-        case 24: launchShade<24>(c, S, count); break;
-        case 32: launchShade<32>(c, S, count); break;
-        default: launchShade<64>(c, S, count); break;
+        case 16: launchShade<16>(c, S, count, f->enable_soft_shadow && f->enable_environment_mapping); break;
+        case 24: launchShade<24>(c, S, count, f->enable_soft_shadow && f->enable_environment_mapping); break;
+        case 32: launchShade<32>(c, S, count, f->enable_soft_shadow && f->enable_environment_mapping); break;
+        default: launchShade<64>(c, S, count, f->enable_soft_shadow && f->enable_environment_mapping); break;
         }
         HIP_TRY(hipGetLastError());
     }
