@@ -39,6 +39,12 @@ RTX_DEV float length(V3 v) { return __builtin_sqrtf(dot(v, v)); }
 RTX_DEV V3 normalize(V3 v) { return v * (1.0f / __builtin_sqrtf(dot(v, v))); }
 RTX_DEV float distance(V3 p0, V3 p1) { return length(p1 - p0); }
 
+// Two floats that one packed instruction (v_pk_add_f32 / v_pk_mul_f32) works on.
+// Each half is an ordinary IEEE single operation, so packing changes the
+// instruction count and nothing else.
+typedef float F2 __attribute__((ext_vector_type(2)));
+RTX_DEV F2 both(float v) { return F2 { v, v }; }
+
 struct Ray {
     V3 o, d;
     float t;
@@ -145,6 +151,40 @@ RTX_DEV bool childTestFinite(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float& key)
     return in || (!miss && !(tmax < first));
 }
 
+// childTestFinite for both children of a node at once.  The device keeps a node as
+// X = (lo0.x, lo1.x, hi0.x, hi1.x), Y, Z likewise: the two children sit in the two
+// halves of packed operands, so the 12 subtractions and 12 multiplications of the
+// two slab tests are 6 + 6 packed instructions.
+RTX_DEV void nodeTestFinite(float4 X, float4 Y, float4 Z, V3 o, V3 inv, float tmax, bool& h0, bool& h1, float& k0, float& k1)
+{
+    const F2 dlx = F2 { X.x, X.y } - both(o.x), dhx = F2 { X.z, X.w } - both(o.x);
+    const F2 dly = F2 { Y.x, Y.y } - both(o.y), dhy = F2 { Y.z, Y.w } - both(o.y);
+    const F2 dlz = F2 { Z.x, Z.y } - both(o.z), dhz = F2 { Z.z, Z.w } - both(o.z);
+    const F2 t0x = dlx * both(inv.x), t1x = dhx * both(inv.x);
+    const F2 t0y = dly * both(inv.y), t1y = dhy * both(inv.y);
+    const F2 t0z = dlz * both(inv.z), t1z = dhz * both(inv.z);
+    {
+        float first = fmaxf(fmaxf(fminf(t0x.x, t1x.x), fminf(t0y.x, t1y.x)), fmaxf(fminf(t0z.x, t1z.x), 0.0f));
+        const float second = fminf(fminf(fmaxf(t0x.x, t1x.x), fmaxf(t0y.x, t1y.x)), fmaxf(t0z.x, t1z.x));
+        const bool miss = first > second;
+        if (first <= 0.0f)
+            first = second;
+        const bool in = fmaxf(fmaxf(dlx.x, dly.x), dlz.x) <= 0.0f && fminf(fminf(dhx.x, dhy.x), dhz.x) >= 0.0f;
+        k0 = in ? 0.0f : first;
+        h0 = in || (!miss && !(tmax < first));
+    }
+    {
+        float first = fmaxf(fmaxf(fminf(t0x.y, t1x.y), fminf(t0y.y, t1y.y)), fmaxf(fminf(t0z.y, t1z.y), 0.0f));
+        const float second = fminf(fminf(fmaxf(t0x.y, t1x.y), fmaxf(t0y.y, t1y.y)), fmaxf(t0z.y, t1z.y));
+        const bool miss = first > second;
+        if (first <= 0.0f)
+            first = second;
+        const bool in = fmaxf(fmaxf(dlx.y, dly.y), dlz.y) <= 0.0f && fminf(fminf(dhx.y, dhy.y), dhz.y) >= 0.0f;
+        k1 = in ? 0.0f : first;
+        h1 = in || (!miss && !(tmax < first));
+    }
+}
+
 // Ray/triangle, src/intersect.cpp:32-89, with the plane (n, D) precomputed on
 // the host by the same arithmetic (src/intersect.cpp:50-58).  A degenerate
 // triangle carries NaN in n and D, which fails `t < tmax` below just as the
@@ -162,6 +202,41 @@ RTX_DEV bool triangleTest(V3 v0, V3 v1, V3 v2, V3 n, float D, V3 o, V3 d, float 
     const float beta = dot(n, cross(p - v0, v2 - v0));
     const float gamma = dot(n, cross(v1 - v0, p - v0));
     if (alpha < 0 || beta < 0 || gamma < 0)
+        return false;
+    tOut = t;
+    return true;
+}
+
+// The same test on the device's triangle record X = (v0.x, v1.x, v2.x, n.x), Y, Z,
+// D, with the operations paired into packed instructions: (dot(n,d), dot(n,o))
+// together, the edge vectors (v2-v0, v2-v1) and (p-v0, p-v1) together, and the two
+// cross products and dot products of beta and alpha together.  Every product, sum
+// and difference is the one triangleTest makes, in the same order; the alpha half
+// is carried negated (a - b and b - a are exact negations of each other, and so
+// are sums of negated terms), so its sign test is flipped.
+RTX_DEV bool triangleTestPacked(float4 X, float4 Y, float4 Z, float D, V3 o, V3 d, float tmax, float& tOut)
+{
+    const F2 nd = (both(X.w) * F2 { d.x, o.x } + both(Y.w) * F2 { d.y, o.y }) + both(Z.w) * F2 { d.z, o.z }; // (n.d, n.o)
+    const float dn = nd.x;
+    if (dn == 0.f)
+        return false;
+    const float t = (D - nd.y) / dn;
+    if (t <= 0.f || !(t < tmax))
+        return false;
+    const float px = o.x + t * d.x, py = o.y + t * d.y, pz = o.z + t * d.z;
+    // e = (p - v0, p - v1); ab = (v2 - v0, v2 - v1); c = v1 - v0
+    const F2 ex = both(px) - F2 { X.x, X.y }, ey = both(py) - F2 { Y.x, Y.y }, ez = both(pz) - F2 { Z.x, Z.y };
+    const F2 abx = both(X.z) - F2 { X.x, X.y }, aby = both(Y.z) - F2 { Y.x, Y.y }, abz = both(Z.z) - F2 { Z.x, Z.y };
+    const float cx = X.y - X.x, cy = Y.y - Y.x, cz = Z.y - Z.x;
+    // first half: cross(p - v0, v2 - v0) (beta); second half: -cross(v2 - v1, p - v1) (-alpha)
+    const F2 wx = ey * abz - aby * ez;
+    const F2 wy = ez * abx - abz * ex;
+    const F2 wz = ex * aby - abx * ey;
+    const F2 ba = (both(X.w) * wx + both(Y.w) * wy) + both(Z.w) * wz; // (beta, -alpha)
+    // gamma = dot(n, cross(v1 - v0, p - v0))
+    const float gx = cy * ez.x - ey.x * cz, gy = cz * ex.x - ez.x * cx, gz = cx * ey.x - ex.x * cy;
+    const float gamma = (X.w * gx + Y.w * gy) + Z.w * gz;
+    if (ba.y > 0 || ba.x < 0 || gamma < 0)
         return false;
     tOut = t;
     return true;
@@ -202,19 +277,22 @@ struct TriRec {
     float d;
     int32_t id, material, flags;
 };
+// The device's triangle record (64 B, leaf order): X = (v0.x, v1.x, v2.x, n.x),
+// Y and Z likewise, W = (D, id, material, flags) -- rtx_tri transposed at upload
+// so that the pairs the packed test works on are neighbours.
 RTX_DEV TriRec loadTri(const DScene& sc, int k)
 {
     const float4* p = sc.tris + size_t(k) * 4;
-    const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+    const float4 X = p[0], Y = p[1], Z = p[2], W = p[3];
     TriRec r;
-    r.v0 = mk(a.x, a.y, a.z);
-    r.v1 = mk(a.w, b.x, b.y);
-    r.v2 = mk(b.z, b.w, c.x);
-    r.n = mk(c.y, c.z, c.w);
-    r.d = e.x;
-    r.id = __float_as_int(e.y);
-    r.material = __float_as_int(e.z);
-    r.flags = __float_as_int(e.w);
+    r.v0 = mk(X.x, Y.x, Z.x);
+    r.v1 = mk(X.y, Y.y, Z.y);
+    r.v2 = mk(X.z, Y.z, Z.z);
+    r.n = mk(X.w, Y.w, Z.w);
+    r.d = W.x;
+    r.id = __float_as_int(W.y);
+    r.material = __float_as_int(W.z);
+    r.flags = __float_as_int(W.w);
     return r;
 }
 
@@ -283,20 +361,20 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
     bool have = true;
     while (have) {
         if (cur >= 0) {
+            // node record: X = (lo0.x, lo1.x, hi0.x, hi1.x), Y, Z likewise, W = (ref0, ref1, -, -)
             const float4* np = sc.nodes + size_t(cur) * 4;
-            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+            const float4 X = np[0], Y = np[1], Z = np[2], W = np[3];
             float k0, k1;
             if (COUNT)
                 tc.boxTests += 2;
             bool h0, h1;
             if (finiteInv) {
-                h0 = childTestFinite(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), o, inv, t, k0);
-                h1 = childTestFinite(mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), o, inv, t, k1);
+                nodeTestFinite(X, Y, Z, o, inv, t, h0, h1, k0, k1);
             } else {
-                h0 = childTest(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), o, inv, t, k0);
-                h1 = childTest(mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), o, inv, t, k1);
+                h0 = childTest(mk(X.x, Y.x, Z.x), mk(X.z, Y.z, Z.z), o, inv, t, k0);
+                h1 = childTest(mk(X.y, Y.y, Z.y), mk(X.w, Y.w, Z.w), o, inv, t, k1);
             }
-            const int32_t r0 = __float_as_int(e.x), r1 = __float_as_int(e.y);
+            const int32_t r0 = __float_as_int(W.x), r1 = __float_as_int(W.y);
             if (h0 && h1) {
                 const bool firstIs1 = k1 < k0;
                 st.push(sp++, firstIs1 ? r0 : r1, firstIs1 ? k0 : k1);
@@ -312,15 +390,16 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
         } else {
             int k = ~cur;
             for (;;) {
-                const TriRec tr = loadTri(sc, k);
+                const float4* p = sc.tris + size_t(k) * 4;
+                const float4 X = p[0], Y = p[1], Z = p[2], W = p[3];
                 if (COUNT)
                     tc.triTests++;
                 float th;
-                if (triangleTest(tr.v0, tr.v1, tr.v2, tr.n, tr.d, o, d, t, th)) {
+                if (triangleTestPacked(X, Y, Z, W.x, o, d, t, th)) {
                     t = th;
                     bestK = k;
                 }
-                if (tr.flags & RTX_TRI_LAST_IN_LEAF)
+                if (__float_as_int(W.w) & RTX_TRI_LAST_IN_LEAF)
                     break;
                 k++;
             }

@@ -1626,8 +1626,30 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     const rtx_node* nodes;
     const rtx_tri* tris;
     const rtx_tri_attr* attrs;
-    int rc = upload(s, d->nodes, d->n_nodes, &nodes);
-    rc = rc ? rc : upload(s, d->tris, d->n_tris, &tris);
+    // device-side record layouts (see loadTri / traverseBvh): both children of a node,
+    // and the three vertices and the normal of a triangle, side by side per axis
+    std::vector<rtx_node> packedNodes(d->n_nodes);
+    for (uint32_t i = 0; i < d->n_nodes; i++) {
+        const rtx_node& a = d->nodes[i];
+        float* o = reinterpret_cast<float*>(&packedNodes[i]);
+        for (int ax = 0; ax < 3; ax++) {
+            o[4 * ax + 0] = a.lo0[ax], o[4 * ax + 1] = a.lo1[ax];
+            o[4 * ax + 2] = a.hi0[ax], o[4 * ax + 3] = a.hi1[ax];
+        }
+        std::memcpy(o + 12, &a.ref0, 16);
+    }
+    std::vector<rtx_tri> packedTris(d->n_tris);
+    for (uint32_t i = 0; i < d->n_tris; i++) {
+        const rtx_tri& a = d->tris[i];
+        float* o = reinterpret_cast<float*>(&packedTris[i]);
+        for (int ax = 0; ax < 3; ax++) {
+            o[4 * ax + 0] = a.v0[ax], o[4 * ax + 1] = a.v1[ax];
+            o[4 * ax + 2] = a.v2[ax], o[4 * ax + 3] = a.n[ax];
+        }
+        std::memcpy(o + 12, &a.d, 16);
+    }
+    int rc = upload(s, packedNodes.data(), d->n_nodes, &nodes);
+    rc = rc ? rc : upload(s, packedTris.data(), d->n_tris, &tris);
     rc = rc ? rc : upload(s, d->tri_attrs, d->n_tris, &attrs);
     rc = rc ? rc : upload(s, idOrder.data(), idOrder.size(), &s->d.idOrder);
     rc = rc ? rc : upload(s, d->materials, d->n_materials, &s->d.mats);
