@@ -8,7 +8,7 @@ ARCH     ?= gfx950
 # -ffp-contract=off: no fused multiply-add on host or device; results must be
 # bit-identical to the reference's plain fp32 arithmetic
 HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -Wno-pass-failed -std=c++17 -fPIC -ffp-contract=off -Iinclude -Iraytracer_amd/csrc
-CXXFLAGS ?= -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude -Iraytracer_amd/host
+CXXFLAGS ?= -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude -Iraytracer_amd/host -pthread
 
 HOST_SRC := $(wildcard raytracer_amd/host/*.cpp)
 HOST_HDR := $(wildcard raytracer_amd/host/*.h) include/rtx.h

@@ -6,6 +6,8 @@
 #include <limits>
 #include <map>
 #include <stdexcept>
+#include <thread>
+#include <unordered_map>
 
 namespace rt {
 namespace {
@@ -30,6 +32,15 @@ Box merge(const Box& a, const Box& b)
     return Box { mn(mn(a.lo, b.lo), mn(a.hi, b.hi)), mx(mx(a.lo, b.lo), mx(a.hi, b.hi)) };
 }
 
+// The build runs in two steps.  ORDER: the reference's recursion
+// (bvhSplitHelper, src/bounding_volume_hierarchy.cpp:101-138) reduced to what
+// decides the tree -- sorting / selecting each node's index range and choosing
+// its split.  A node's two halves are disjoint ranges, so big subtrees are ordered
+// by separate threads; each range is still sorted by the same std::sort call on
+// the same sequence as in a serial build, so the result does not depend on the
+// thread count.  EMIT: the final index order IS the leaf order, so the triangle
+// records are written independently of each other (threads again), and the nodes
+// are numbered in one cheap depth-first pass over the recorded splits.
 struct Builder {
     const Scene& scene;
     const std::vector<Prim>& prims;
@@ -42,8 +53,58 @@ struct Builder {
         Box box;
         int levels, leaves;
     };
+    struct Split {
+        uint64_t key; // range start * 64 + depth: unique per inner node
+        size_t at;
+    };
+    static constexpr size_t kParallelAbove = 1u << 17; // triangles in a subtree worth a thread of its own
+    static constexpr int kParallelDepth = 5;           // at most 2^5 ordering threads
 
-    void emitTriangle(size_t id, bool last)
+    bool isLeaf(size_t n, int depth) const { return (maxDepth > -1 && maxDepth <= depth) || n < 2; }
+
+    void order(size_t* idx, size_t begin, size_t n, int direction, int depth, std::vector<Split>& splits)
+    {
+        if (isLeaf(n, depth))
+            return;
+        size_t* r = idx + begin;
+        auto cmp = [this, direction](const size_t a, const size_t b) {
+            return prims[a].centroid[direction] > prims[b].centroid[direction];
+        };
+        size_t split;
+        if (sah) {
+            // getSAHBestSplit, src/bounding_volume_hierarchy.cpp:76-98
+            std::sort(r, r + n, cmp);
+            const float minimum = prims[r[0]].centroid[direction], maximum = prims[r[n - 1]].centroid[direction];
+            float minCost = std::numeric_limits<float>::infinity();
+            size_t minIndex = 0;
+            for (size_t i = 1; i < n; i++) {
+                const float cost = -((prims[r[i - 1]].centroid[direction] - minimum) * i + (maximum - prims[r[i]].centroid[direction]) * (n - i));
+                if (minCost > cost) {
+                    minCost = cost;
+                    minIndex = i;
+                }
+            }
+            split = minIndex;
+        } else {
+            // getMedian, src/bounding_volume_hierarchy.cpp:65-73
+            std::nth_element(r, r + n / 2, r + n, cmp);
+            split = n / 2;
+        }
+        splits.push_back(Split { uint64_t(begin) * 64u + uint64_t(depth), split });
+        const int next = (direction + 1) % 3;
+        if (n >= kParallelAbove && depth < kParallelDepth) {
+            std::vector<Split> other;
+            std::thread t([&] { order(idx, begin + split, n - split, next, depth + 1, other); });
+            order(idx, begin, split, next, depth + 1, splits);
+            t.join();
+            splits.insert(splits.end(), other.begin(), other.end());
+        } else {
+            order(idx, begin, split, next, depth + 1, splits);
+            order(idx, begin + split, n - split, next, depth + 1, splits);
+        }
+    }
+
+    void writeTriangle(size_t slot, size_t id, bool last)
     {
         const Prim& p = prims[id];
         const Mesh& m = scene.meshes[size_t(p.mesh)];
@@ -68,7 +129,7 @@ struct Builder {
         r.id = int32_t(id);
         r.material = p.mesh; // one material per mesh
         r.flags = last ? RTX_TRI_LAST_IN_LEAF : 0;
-        out.tris.push_back(r);
+        out.tris[slot] = r;
         rtx_tri_attr at;
         std::memcpy(at.n0, &a.normal, 12);
         std::memcpy(at.n1, &b.normal, 12);
@@ -77,48 +138,24 @@ struct Builder {
         std::memcpy(at.uv1, &b.texCoord, 8);
         std::memcpy(at.uv2, &c.texCoord, 8);
         at.pad = 0.f;
-        out.attrs.push_back(at);
+        out.attrs[slot] = at;
     }
 
-    // bvhSplitHelper, src/bounding_volume_hierarchy.cpp:101-138
-    Sub build(size_t* idx, size_t n, int direction, int depth)
+    // nodes in depth-first pre-order; marks the last triangle of every leaf
+    Sub number(const size_t* idx, size_t begin, size_t n, int depth, const std::unordered_map<uint64_t, size_t>& splitOf, std::vector<uint8_t>& lastInLeaf)
     {
-        if ((maxDepth > -1 && maxDepth <= depth) || n < 2) {
-            Box box = prims[idx[0]].box;
+        if (isLeaf(n, depth)) {
+            Box box = prims[idx[begin]].box;
             for (size_t i = 0; i < n; i++)
-                box = merge(box, prims[idx[i]].box);
-            const int32_t first = int32_t(out.tris.size());
-            for (size_t i = 0; i < n; i++)
-                emitTriangle(idx[i], i + 1 == n);
-            return Sub { ~first, int32_t(n), box, 1, 1 };
+                box = merge(box, prims[idx[begin + i]].box);
+            lastInLeaf[begin + n - 1] = 1;
+            return Sub { ~int32_t(begin), int32_t(n), box, 1, 1 };
         }
-        auto cmp = [this, direction](const size_t a, const size_t b) {
-            return prims[a].centroid[direction] > prims[b].centroid[direction];
-        };
-        size_t split;
-        if (sah) {
-            // getSAHBestSplit, src/bounding_volume_hierarchy.cpp:76-98
-            std::sort(idx, idx + n, cmp);
-            const float minimum = prims[idx[0]].centroid[direction], maximum = prims[idx[n - 1]].centroid[direction];
-            float minCost = std::numeric_limits<float>::infinity();
-            size_t minIndex = 0;
-            for (size_t i = 1; i < n; i++) {
-                const float cost = -((prims[idx[i - 1]].centroid[direction] - minimum) * i + (maximum - prims[idx[i]].centroid[direction]) * (n - i));
-                if (minCost > cost) {
-                    minCost = cost;
-                    minIndex = i;
-                }
-            }
-            split = minIndex;
-        } else {
-            // getMedian, src/bounding_volume_hierarchy.cpp:65-73
-            std::nth_element(idx, idx + n / 2, idx + n, cmp);
-            split = n / 2;
-        }
+        const size_t split = splitOf.at(uint64_t(begin) * 64u + uint64_t(depth));
         const int32_t self = int32_t(out.nodes.size());
         out.nodes.emplace_back();
-        const Sub l = build(idx, split, (direction + 1) % 3, depth + 1);
-        const Sub r = build(idx + split, n - split, (direction + 1) % 3, depth + 1);
+        const Sub l = number(idx, begin, split, depth + 1, splitOf, lastInLeaf);
+        const Sub r = number(idx, begin + split, n - split, depth + 1, splitOf, lastInLeaf);
         rtx_node& nd = out.nodes[size_t(self)];
         std::memcpy(nd.lo0, &l.box.lo, 12);
         std::memcpy(nd.hi0, &l.box.hi, 12);
@@ -129,6 +166,32 @@ struct Builder {
         nd.cnt0 = l.ref < 0 ? l.cnt : 0;
         nd.cnt1 = r.ref < 0 ? r.cnt : 0;
         return Sub { self, 0, merge(l.box, r.box), std::max(l.levels, r.levels) + 1, l.leaves + r.leaves };
+    }
+
+    Sub build(size_t* idx, size_t n)
+    {
+        std::vector<Split> splits;
+        order(idx, 0, n, 0, 0, splits);
+        std::unordered_map<uint64_t, size_t> splitOf;
+        splitOf.reserve(splits.size() * 2);
+        for (const Split& s : splits)
+            splitOf.emplace(s.key, s.at);
+        std::vector<uint8_t> lastInLeaf(n, 0);
+        const Sub root = number(idx, 0, n, 0, splitOf, lastInLeaf);
+        out.tris.resize(n);
+        out.attrs.resize(n);
+        const size_t nThreads = n >= kParallelAbove ? std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16) : 1;
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < nThreads; w++)
+            pool.emplace_back([&, w] {
+                for (size_t k = n * w / nThreads; k < n * (w + 1) / nThreads; k++)
+                    writeTriangle(k, idx[k], lastInLeaf[k] != 0);
+            });
+        for (size_t k = 0; k < n / nThreads; k++)
+            writeTriangle(k, idx[k], lastInLeaf[k] != 0);
+        for (std::thread& t : pool)
+            t.join();
+        return root;
     }
 };
 
@@ -317,13 +380,11 @@ FlatScene flattenScene(const Scene& scene, const Features& features)
     std::vector<size_t> idx(n);
     for (size_t i = 0; i < n; i++)
         idx[i] = i;
-    out.tris.reserve(n);
-    out.attrs.reserve(n);
-    out.nodes.reserve(n);
+    out.nodes.reserve(n / 2 + 1);
     // glm::ceil(0.8 * glm::log2((float) n)), src/bounding_volume_hierarchy.cpp:177
     const int maxDepth = int(std::ceil(0.8 * double(std::log2(float(n)))));
     Builder b { scene, prims, out, maxDepth, features.extra.enableBvhSahBinning };
-    const Builder::Sub root = b.build(idx.data(), n, 0, 0);
+    const Builder::Sub root = b.build(idx.data(), n);
     out.rootRef = root.ref;
     out.rootCnt = root.ref < 0 ? root.cnt : 0;
     std::memcpy(out.rootLo, &root.box.lo, 12);

@@ -43,6 +43,35 @@ def test_flattener_builds_the_reference_tree(golden_bvh, scene_name):
         flat.close()
 
 
+def test_threaded_build_of_a_large_mesh_is_the_serial_tree():
+    """Above 131072 triangles the flattener orders subtrees on several threads; the
+    tree must still be the one the (serial) CPU restatement of the reference builds."""
+    scene = SceneData()
+    scene.meshes.append(dragon_standin(seed=3, subdivisions=7))     # 327 680 triangles
+    for sah in (1, 0):
+        f = abi.features(accel_structure=1, bvh_sah_binning=sah)
+        flat = engine.flatten(scene, f)
+        orc = OracleEngine(scene, f)
+        assert [flat.num_levels, flat.num_leaves] == [orc.levels(), orc.leaves()]
+        d = orc.dump()
+        order = []
+
+        def rec(i):
+            ch = d["children"][d["offsets"][i]:d["offsets"][i + 1]]
+            if d["leaf"][i]:
+                order.extend(int(c) for c in ch)
+                return
+            rec(int(ch[0]))
+            rec(int(ch[1]))
+
+        sys.setrecursionlimit(100000)
+        rec(d["root"])
+        orc.close()
+        assert flat.tris["id"].tolist() == order          # leaf order = depth-first order of the reference tree
+        assert int((flat.tris["flags"] & 1).sum()) == flat.num_leaves
+        flat.close()
+
+
 def test_triangle_records_carry_the_reference_plane():
     """n and D of every record equal what intersectRayWithTriangle computes per test
     (src/intersect.cpp:50-58); degenerate triangles are encoded as NaN planes."""
