@@ -13,8 +13,8 @@ CXXFLAGS ?= -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude -Iray
 HOST_SRC := $(wildcard raytracer_amd/host/*.cpp)
 HOST_HDR := $(wildcard raytracer_amd/host/*.h) include/rtx.h
 
-.PHONY: all hip host oracle clean
-all: hip host oracle
+.PHONY: all hip host examples oracle clean
+all: hip host examples oracle
 
 hip: raytracer_amd/librtx_hip.so
 raytracer_amd/librtx_hip.so: raytracer_amd/csrc/rtx_hip.hip raytracer_amd/csrc/rtx_device.hpp include/rtx.h
@@ -22,7 +22,12 @@ raytracer_amd/librtx_hip.so: raytracer_amd/csrc/rtx_hip.hip raytracer_amd/csrc/r
 
 host: raytracer_amd/librtx_host.so
 raytracer_amd/librtx_host.so: $(HOST_SRC) $(HOST_HDR) raytracer_amd/librtx_hip.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -Lraytracer_amd -lrtx_hip -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -Lraytracer_amd -lrtx_hip -lz -Wl,-rpath,'$$ORIGIN'
+
+# headless example: OBJ in, BMP out, through the reference-shaped C++ API
+examples: raytracer_amd/render_obj
+raytracer_amd/render_obj: examples/render_obj.cpp raytracer_amd/librtx_host.so
+	$(CXX) $(CXXFLAGS) -o $@ examples/render_obj.cpp -Lraytracer_amd -lrtx_host -lrtx_hip -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle all

@@ -267,9 +267,25 @@ class RefEngine(_Engine):
 
     def close(self):
         if self.h:
-            self.fn("bvh_free")(vp(self.b))
+            if self.b:
+                self.fn("bvh_free")(vp(self.b))
             self.fn("scene_free")(vp(self.h))
             self.h = None
+
+    @classmethod
+    def load_obj(cls, path, normalize=False) -> SceneData:
+        """The reference's own loadMesh (framework/src/mesh.cpp:52-149) on an OBJ file."""
+        e = cls.__new__(cls)
+        fn = e.fn("scene_load_obj")
+        fn.restype = vp
+        e.h = fn(str(path).encode(), int(bool(normalize)))
+        if not e.h:
+            raise RuntimeError("the reference's loader rejected " + str(path))
+        e.b = None
+        try:
+            return e.export_scene()
+        finally:
+            e.close()
 
     def set_envmap(self, image, mapping, vfov_degrees, background):
         img = None if image is None else np.ascontiguousarray(image, np.float32)

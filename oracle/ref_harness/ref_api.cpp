@@ -109,6 +109,17 @@ void* ref_scene_prebuilt(int sceneType)
 }
 
 void* ref_scene_empty() { return new RefScene; }
+// loadMesh (framework/src/mesh.cpp:52-149) on an arbitrary OBJ file; NULL on failure
+void* ref_scene_load_obj(const char* path, int centerAndNormalize)
+{
+    try {
+        auto* s = new RefScene;
+        s->scene.meshes = loadMesh(path, centerAndNormalize != 0);
+        return s;
+    } catch (...) {
+        return nullptr;
+    }
+}
 void ref_scene_free(void* p) { delete static_cast<RefScene*>(p); }
 
 // verts: nv x 8 floats (position, normal, texCoord); mat: kd3 ks3 shininess transparency

@@ -254,3 +254,34 @@ def device_camera(cam: abi.Camera, width, height) -> abi.Camera:
     out = abi.Camera()
     host_lib().rtxh_camera(C.byref(cam), int(width), int(height), C.byref(out))
     return out
+
+
+def load_obj(path, normalize=False) -> "SceneData":
+    """loadMesh (framework/src/mesh.cpp:52-176) through the native host loader:
+    the meshes of an OBJ / MTL file (PNG textures decoded) as a SceneData."""
+    from .scene import SceneData
+    lib = host_lib()
+    h = lib.rtxh_scene_create()
+    try:
+        _check(lib.rtxh_scene_load_obj(vp(h), str(path).encode(), int(bool(normalize))), "load_obj")
+        s = SceneData()
+        for m in range(lib.rtxh_scene_num_meshes(vp(h))):
+            nv, nt, tw, th = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            lib.rtxh_mesh_sizes(vp(h), m, C.byref(nv), C.byref(nt), C.byref(tw), C.byref(th))
+            v, t, mat = np.zeros((nv.value, 8), np.float32), np.zeros((nt.value, 3), np.uint32), np.zeros(8, np.float32)
+            tex = np.zeros((th.value, tw.value, 3), np.float32) if tw.value else None
+            lib.rtxh_mesh_copy(vp(h), m, _ptr(v), _ptr(t), _ptr(mat), _ptr(tex))
+            s.add_mesh(v, t, mat, tex)
+        return s
+    finally:
+        lib.rtxh_scene_free(vp(h))
+
+
+def load_image(path):
+    """Image (framework/src/image.cpp:13-36): (h, w, 3) float32 in [0, 1] from an 8-bit PNG."""
+    lib = host_lib()
+    w, h = C.c_int(), C.c_int()
+    _check(lib.rtxh_image_load(str(path).encode(), C.byref(w), C.byref(h), None), "load_image")
+    out = np.zeros((h.value, w.value, 3), np.float32)
+    _check(lib.rtxh_image_load(str(path).encode(), C.byref(w), C.byref(h), _ptr(out)), "load_image")
+    return out

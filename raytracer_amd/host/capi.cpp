@@ -7,6 +7,7 @@
 #include <string>
 
 #include "raytracer.h"
+#include "scene_io.h"
 
 using namespace rt;
 
@@ -112,6 +113,53 @@ int rtxh_scene_add_mesh(void* p, const float* verts, int nv, const uint32_t* tri
         }
         m.material = toMaterial(mat, tex, tw, th);
         s->scene.meshes.push_back(std::move(m));
+    });
+}
+
+// loadMesh (framework/src/mesh.cpp:52-149): append the meshes of an OBJ file
+int rtxh_scene_load_obj(void* p, const char* path, int centerAndNormalize)
+{
+    return guarded([&] {
+        auto* s = static_cast<HostScene*>(p);
+        for (Mesh& m : loadMesh(path, centerAndNormalize != 0))
+            s->scene.meshes.push_back(std::move(m));
+    });
+}
+int rtxh_scene_num_meshes(const void* p) { return int(static_cast<const HostScene*>(p)->scene.meshes.size()); }
+void rtxh_mesh_sizes(const void* p, int m, int* nv, int* nt, int* tw, int* th)
+{
+    const Mesh& mesh = static_cast<const HostScene*>(p)->scene.meshes[size_t(m)];
+    *nv = int(mesh.vertices.size());
+    *nt = int(mesh.triangles.size());
+    *tw = mesh.material.kdTexture ? mesh.material.kdTexture->width : 0;
+    *th = mesh.material.kdTexture ? mesh.material.kdTexture->height : 0;
+}
+// verts: nv x 8 (position, normal, uv); tris: nt x 3; mat: kd, ks, shininess, transparency; tex: th x tw x 3 or NULL
+void rtxh_mesh_copy(const void* p, int m, float* verts, uint32_t* tris, float* mat, float* tex)
+{
+    const Mesh& mesh = static_cast<const HostScene*>(p)->scene.meshes[size_t(m)];
+    for (size_t i = 0; i < mesh.vertices.size(); i++) {
+        const Vertex& v = mesh.vertices[i];
+        const float row[8] = { v.position.x, v.position.y, v.position.z, v.normal.x, v.normal.y, v.normal.z, v.texCoord.x, v.texCoord.y };
+        std::memcpy(verts + 8 * i, row, sizeof(row));
+    }
+    for (size_t i = 0; i < mesh.triangles.size(); i++)
+        tris[3 * i] = mesh.triangles[i].x, tris[3 * i + 1] = mesh.triangles[i].y, tris[3 * i + 2] = mesh.triangles[i].z;
+    const Material& mt = mesh.material;
+    const float mrow[8] = { mt.kd.x, mt.kd.y, mt.kd.z, mt.ks.x, mt.ks.y, mt.ks.z, mt.shininess, mt.transparency };
+    std::memcpy(mat, mrow, sizeof(mrow));
+    if (tex && mt.kdTexture)
+        std::memcpy(tex, static_cast<const void*>(mt.kdTexture->pixels.data()), mt.kdTexture->pixels.size() * 12);
+}
+// Image (framework/src/image.cpp:13-36): size query with rgb == NULL, then the pixels
+int rtxh_image_load(const char* path, int* w, int* h, float* rgb)
+{
+    return guarded([&] {
+        const Image img = loadImage(path);
+        *w = img.width;
+        *h = img.height;
+        if (rgb)
+            std::memcpy(rgb, static_cast<const void*>(img.pixels.data()), img.pixels.size() * 12);
     });
 }
 

@@ -192,3 +192,23 @@ def dragon_scene(seed=1, subdivisions=6):
     s.meshes.append(dragon_standin(seed, subdivisions))
     s.lights.append(abi.point_light((-1, 1, -1), (1, 1, 1)))
     return s
+
+
+def instanced_scene(copies, seed=1, subdivisions=6, transparent_every=3):
+    """BASELINE configs[4] stand-in: `copies` instances of the seeded mesh baked to
+    flat triangles on a jittered cubic grid inside the unit cube (122 copies =
+    9 994 240 triangles), every `transparent_every`-th one with transparency 0.6,
+    one point light."""
+    base = dragon_standin(seed, subdivisions)
+    rng = np.random.default_rng(seed)
+    s = SceneData()
+    g = int(np.ceil(copies ** (1 / 3)))
+    for i in range(copies):
+        v = base.vertices.copy()
+        c = np.array([i % g, (i // g) % g, i // (g * g)], np.float32) / np.float32(g) - np.float32(0.5) + np.float32(0.5 / g)
+        c = c + rng.uniform(-0.02, 0.02, 3).astype(np.float32)
+        v[:, :3] = v[:, :3] * np.float32(0.8 / g) + c
+        alpha = 0.6 if transparent_every and i % transparent_every == 0 else 1.0
+        s.add_mesh(v, base.triangles.copy(), (0.8, 0.6, 0.4, 0.0, 0.0, 0.0, 1.0, alpha))
+    s.lights.append(abi.point_light((-1, 1, -1), (1, 1, 1)))
+    return s

@@ -20,6 +20,7 @@ Outputs (all data, no reference source):
                         barycentric, shading, reflection, textures, mip chain,
                         environment map, light sampling, glossy fan, RNG stream)
 """
+import ctypes as C
 import os
 import sys
 
@@ -126,6 +127,129 @@ def make_shade():
         ref.close()
         print("shade", name, float(np.nansum(out[name])))
     np.savez_compressed(os.path.join(OUT, "shade.npz"), **out)
+
+
+def _png(path, pixels, color_type, palette=None, seed=0, depth=8):
+    """A PNG file written by hand (zlib + per-row filters chosen at random, so the
+    reader's unfiltering is exercised).  pixels: (h, w, channels) sample values."""
+    import struct
+    import zlib
+    h, w, ch = pixels.shape
+    rng = np.random.default_rng(seed)
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+    samples = pixels.reshape(h, w * ch).astype(int)
+    if depth == 8:
+        flat = samples
+    elif depth == 16:
+        flat = np.stack([samples >> 8, samples & 255], 2).reshape(h, -1)
+    else:
+        per = 8 // depth
+        padded = np.zeros((h, (w * ch + per - 1) // per * per), int)
+        padded[:, :w * ch] = samples
+        flat = sum(padded[:, k::per] << (8 - depth * (k + 1)) for k in range(per))
+    unit = max(1, ch * depth // 8)
+    raw = bytearray()
+    for y in range(h):
+        ft = int(rng.integers(0, 5))
+        raw.append(ft)
+        for i in range(flat.shape[1]):
+            a = flat[y, i - unit] if i >= unit else 0
+            b = flat[y - 1, i] if y else 0
+            c = flat[y - 1, i - unit] if (y and i >= unit) else 0
+            pred = [0, a, b, (a + b) // 2, paeth(a, b, c)][ft]
+            raw.append((flat[y, i] - pred) & 255)
+    body = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 0))
+    if palette is not None:
+        body += chunk(b"PLTE", bytes(np.asarray(palette, np.uint8).ravel()))
+    comp = zlib.compress(bytes(raw), 6)
+    half = len(comp) // 2
+    body += chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")
+    with open(path, "wb") as fh:
+        fh.write(body)
+
+
+OBJ_CASES = [("mixed", False), ("mixed", True), ("plain", True), ("plain", False)]
+
+
+def make_obj():
+    """Synthetic OBJ / MTL / PNG files (written here, seeded) and what the reference's
+    loader (tinyobjloader + framework/src/mesh.cpp + stb_image) makes of them."""
+    d = os.path.join(OUT, "obj")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(21)
+    _png(os.path.join(d, "rgb.png"), rng.integers(0, 256, (9, 14, 3), dtype=np.uint8), 2, seed=1)
+    _png(os.path.join(d, "rgba.png"), rng.integers(0, 256, (8, 8, 4), dtype=np.uint8), 6, seed=2)
+    _png(os.path.join(d, "grey_alpha.png"), rng.integers(0, 256, (5, 7, 2), dtype=np.uint8), 4, seed=3)
+    _png(os.path.join(d, "grey.png"), rng.integers(0, 256, (6, 6, 1), dtype=np.uint8), 0, seed=4)
+    _png(os.path.join(d, "palette.png"), rng.integers(0, 16, (7, 5, 1), dtype=np.uint8), 3, palette=rng.integers(0, 256, (16, 3)), seed=5)
+    _png(os.path.join(d, "palette1.png"), rng.integers(0, 2, (9, 11, 1)), 3, palette=rng.integers(0, 256, (2, 3)), seed=6, depth=1)
+    _png(os.path.join(d, "palette4.png"), rng.integers(0, 16, (5, 7, 1)), 3, palette=rng.integers(0, 256, (16, 3)), seed=7, depth=4)
+    _png(os.path.join(d, "grey2.png"), rng.integers(0, 4, (6, 9, 1)), 0, seed=8, depth=2)
+    _png(os.path.join(d, "grey4.png"), rng.integers(0, 16, (4, 5, 1)), 0, seed=9, depth=4)
+    _png(os.path.join(d, "rgb16.png"), rng.integers(0, 65536, (5, 6, 3)), 2, seed=10, depth=16)
+    _png(os.path.join(d, "grey16.png"), rng.integers(0, 65536, (4, 4, 1)), 0, seed=11, depth=16)
+    with open(os.path.join(d, "mixed.mtl"), "w") as fh:
+        fh.write("# materials of mixed.obj\n"
+                 "newmtl red\nKd 0.8 0.1 0.05\nKs 0.5 0.5 0.25\nNs 96.078431\nd 0.7\n\n"
+                 "newmtl textured\nKa 0 0 0\nmap_Kd rgb.png\nKs .125 1e-1 2.5E-1\nTr 0.25\n"
+                 "newmtl late_kd\nmap_Kd palette.png\nKd 0.2 0.3 0.4\nNs 1.5e1\nTr 0.1\nd 0.9\n"
+                 "newmtl grey\nKd 1 1 1\nmap_Kd grey_alpha.png\n")
+    v = rng.uniform(-2, 2, (40, 3))
+    lines = ["# seeded test mesh", "mtllib mixed.mtl", "o first"]
+    fmts = ["%.6f", "%.3f", "%.9f", "%e", "%.2E", "%g"]
+    for i, p in enumerate(v):
+        lines.append("v " + " ".join(fmts[(i + k) % len(fmts)] % c for k, c in enumerate(p)))
+    lines += ["v .5 -.25 +1.", "v 1e0 2E+0 -3e-0", "v 0.1234567890123 12345.678 -0.000001234"]      # 41, 42, 43 (1-based)
+    for i in range(12):
+        n = rng.normal(size=3)
+        lines.append("vn %.5f %.5f %.5f" % tuple(n / np.linalg.norm(n)))
+    for i in range(10):
+        lines.append("vt %.4f %.4f" % tuple(rng.uniform(-0.5, 1.5, 2)))
+    lines += ["usemtl red", "f 1/1/1 2/2/2 3/3/3", "f 2/2/2 3/3/3 4/4/4", "f 4//5 5//6 6//7", "f 7/3 8/4 9/5",
+              "f 10 11 12", "f 1/1/1 5/6/2 9/3/3 13/4/4",                    # a quad
+              "usemtl textured", "f 14/1/1 15/2/1 16/3/1 17/4/1", "f 18/5 19/6 20/7", "f -1 -2 -3", "f -4/-1/-1 -5/-2/-2 -6/-3/-3",
+              "usemtl nosuchmaterial", "f 21 22 23", "f 22 23 24",
+              "g second group", "f 25/8/9 26/9/10 27/10/11", "usemtl late_kd", "f 28 29 30", "f 29 30 31 32",
+              "usemtl grey", "f 33 34 35",                                    # a material change on the last triangle of the shape
+              "g third", "usemtl red", "f 36/1/1 37/2/2 38/3/3", "f 36/1/1 37/2/2 38/3/3", "f 38/3/3 39/4/4 40/5/5", "s off", "l 1 2"]
+    with open(os.path.join(d, "mixed.obj"), "w") as fh:
+        fh.write("\r\n".join(lines[:20]) + "\r\n" + "\n".join(lines[20:]) + "\n")
+    # no normals, no materials, every face its own copy of the corner vertices -> de-duplication
+    grid = [(x, y) for y in range(5) for x in range(6)]
+    lines = ["# plain grid, bent"]
+    for x, y in grid:
+        lines.append("v %d %d %.3f" % (x, y, 0.3 * np.sin(x) * np.cos(y)))
+    for y in range(4):
+        for x in range(5):
+            a, b, c, e = 1 + y * 6 + x, 2 + y * 6 + x, 8 + y * 6 + x, 7 + y * 6 + x
+            lines.append("f %d %d %d %d" % (a, b, c, e) if (x + y) % 2 else "f %d %d %d" % (a, b, c))
+            if not (x + y) % 2:
+                lines.append("f %d %d %d" % (a, c, e))
+    with open(os.path.join(d, "plain.obj"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    for name, norm in OBJ_CASES:
+        s = RefEngine.load_obj(os.path.join(d, name + ".obj"), norm)
+        s.save(os.path.join(d, f"{name}_{'normalized' if norm else 'raw'}.npz"))
+        print("obj", name, norm, [(len(m.vertices), len(m.triangles)) for m in s.meshes])
+    imgs = {}
+    R = RefEngine.__new__(RefEngine)
+    for png in ("rgb", "rgba", "grey_alpha", "grey", "palette", "palette1", "palette4", "grey2", "grey4", "rgb16", "grey16"):
+        path = os.path.join(d, png + ".png").encode()
+        w, h = C.c_int(), C.c_int()
+        fn = R.fn("image_load")
+        fn(path, C.byref(w), C.byref(h), None)
+        out = np.zeros((h.value, w.value, 3), np.float32)
+        fn(path, C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p))
+        imgs[png] = out
+    np.savez_compressed(os.path.join(d, "images.npz"), **imgs)
 
 
 def make_kat():
@@ -282,6 +406,6 @@ def make_kat():
 if __name__ == "__main__":
     if not have_ref():
         sys.exit("oracle/_ref/libref.so is missing: run `make -C oracle ref` where /root/reference exists")
-    what = sys.argv[1:] or ["scenes", "bvh", "rays", "images", "shade", "kat"]
+    what = sys.argv[1:] or ["scenes", "bvh", "rays", "images", "shade", "kat", "obj"]
     for w in what:
         globals()["make_" + w]()

@@ -212,6 +212,33 @@ def test_compact_tiles_and_detile_on_device(gpu_device):
     gpu.close()
 
 
+def test_headless_example_renders_an_obj_to_a_bitmap(gpu_device, tmp_path):
+    """examples/render_obj.cpp: OBJ in, BMP out through the C++ host API; the bitmap
+    holds the frame the same scene gives through the Python driver (8-bit, clamped)."""
+    import os
+    import subprocess
+    from raytracer_amd import engine
+    exe = os.path.join(os.path.dirname(engine.HIP_SO), "render_obj")
+    assert os.path.exists(exe), "raytracer_amd/render_obj not built (make examples)"
+    obj = os.path.join(cases.GOLDEN, "obj", "mixed.obj")
+    out = str(tmp_path / "mixed.bmp")
+    r = subprocess.run([exe, obj, out, "96", "64"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr
+    raw = open(out, "rb").read()
+    assert raw[:2] == b"BM" and int.from_bytes(raw[18:22], "little") == 96 and abs(int.from_bytes(raw[22:26], "little", signed=True)) == 64
+    scene = engine.load_obj(obj, normalize=True)
+    scene.lights = [abi.point_light((-1, 1, -1), (1, 1, 1))]
+    f = abi.features(**cases.BASE)
+    gpu = GpuEngine(scene, f)
+    img = gpu.render(make_camera(), f, make_params(96, 64))
+    gpu.close()
+    want = (np.clip(img, 0, 1) * 255).astype(np.uint8)           # src/screen.cpp:45-56: clamp, scale, truncate
+    off = int.from_bytes(raw[10:14], "little")
+    px = np.frombuffer(raw[off:off + 96 * 64 * 4], np.uint8).reshape(64, 96, 4)
+    rows = px if int.from_bytes(raw[22:26], "little", signed=True) < 0 else px[::-1]
+    assert np.array_equal(rows[..., :3][..., ::-1], want) or np.array_equal(rows[..., :3], want)
+
+
 def test_bvh_interface_single_ray_hitinfo(gpu_device):
     """BvhInterface::intersect(Ray&, HitInfo&, Features): ray.t in/out, HitInfo filled."""
     scene = cases.load_scene("cornell")
