@@ -239,6 +239,77 @@ def test_headless_example_renders_an_obj_to_a_bitmap(gpu_device, tmp_path):
     assert np.array_equal(rows[..., :3][..., ::-1], want) or np.array_equal(rows[..., :3], want)
 
 
+def test_c_abi_rejects_bad_input(gpu_device):
+    """Error behaviour of the C ABI: a negative status and a message, never a launch,
+    for NULL arguments, unknown drivers, limits and inconsistent scene descriptions."""
+    import ctypes as C
+    from raytracer_amd import engine
+    hip = engine.hip_lib()
+    scene = cases.load_scene("cube")
+    f = abi.features(**cases.BASE)
+    gpu = GpuEngine(scene, f)
+    dsc = gpu.device_scene()
+    cam = engine.device_camera(make_camera(), 32, 32)
+    out = np.zeros((32, 32, 3), np.float32)
+    outp = out.ctypes.data_as(C.c_void_p)
+
+    def render(rp, feat=f, cam_=cam, scene_=dsc, out_=outp):
+        return hip.rtx_render(scene_, C.byref(cam_) if cam_ is not None else None, C.byref(feat), C.byref(rp), out_, None)
+
+    assert render(make_params(32, 32)) == 0
+    assert render(make_params(32, 32), out_=None) == -1 and b"NULL" in hip.rtx_last_error()
+    assert render(make_params(32, 32), scene_=None) == -1
+    assert render(make_params(32, 32, driver=9)) == -1 and b"driver" in hip.rtx_last_error()
+    assert render(make_params(0, 32)) == -1 and b"frame size" in hip.rtx_last_error()
+    assert render(make_params(32, 32, tile_size=12)) == -1 and b"multiple of 8" in hip.rtx_last_error()
+    assert render(make_params(32, 32, tile_world=2, tile_rank=2)) == -1 and b"tile_rank" in hip.rtx_last_error()
+    assert render(make_params(32, 32, ray_depth=9)) == -3 and b"ray_depth" in hip.rtx_last_error()
+    soft_env = abi.features(**dict(cases.BASE, soft_shadow=1, environment_mapping=1))
+    assert render(make_params(32, 32, shadow_samples=810), feat=soft_env) == -3 and b"shadow_samples" in hip.rtx_last_error()
+    assert render(make_params(32, 32, shadow_samples=809), feat=soft_env) == 0
+    # nothing was written by the rejected calls, and the accepted ones still work
+    assert np.isfinite(out).all()
+    rays = np.zeros(4, abi.RAY_DTYPE)
+    hits = np.zeros(4, abi.HIT_DTYPE)
+    assert hip.rtx_trace(dsc, rays.ctypes.data_as(C.c_void_p), C.c_size_t(4), None, C.byref(f), None) == -1
+    assert hip.rtx_trace(dsc, None, C.c_size_t(0), None, C.byref(f), None) == 0      # empty batch: nothing to point at
+    assert hip.rtx_shade(dsc, rays.ctypes.data_as(C.c_void_p), C.c_size_t(4), C.byref(f), C.byref(make_params(1, 1)), None, None) == -1
+
+    # inconsistent scene descriptions are refused at creation
+    flat = engine.flatten(scene, f)
+    for breakage, word in (("ref", b"reference"), ("material", b"material"), ("flag", b"last"), ("light", b"light"), ("bins", b"bins")):
+        d = flat.desc()
+        keep = []
+        if breakage == "ref":
+            arr = np.ctypeslib.as_array(C.cast(d.nodes, C.POINTER(C.c_int32)), shape=(d.n_nodes, 16)).copy()
+            arr[0, 12] = 10 ** 6
+            keep.append(arr)
+            d.nodes = arr.ctypes.data
+        elif breakage == "material":
+            arr = np.ctypeslib.as_array(C.cast(d.tris, C.POINTER(C.c_int32)), shape=(d.n_tris, 16)).copy()
+            arr[3, 14] = 77
+            keep.append(arr)
+            d.tris = arr.ctypes.data
+        elif breakage == "flag":
+            arr = np.ctypeslib.as_array(C.cast(d.tris, C.POINTER(C.c_int32)), shape=(d.n_tris, 16)).copy()
+            arr[-1, 15] = 0
+            keep.append(arr)
+            d.tris = arr.ctypes.data
+        elif breakage == "light":
+            arr = np.ctypeslib.as_array(C.cast(d.lights, C.POINTER(C.c_int32)), shape=(d.n_lights, 24)).copy()
+            arr[0, 0] = 5
+            keep.append(arr)
+            d.lights = arr.ctypes.data
+        else:
+            d.n_env_bins = 3
+            d.env_bins = None
+        h = hip.rtx_scene_create(C.byref(d))
+        assert not h, breakage
+        assert word in hip.rtx_last_error().lower(), (breakage, hip.rtx_last_error())
+    flat.close()
+    gpu.close()
+
+
 def test_bvh_interface_single_ray_hitinfo(gpu_device):
     """BvhInterface::intersect(Ray&, HitInfo&, Features): ray.t in/out, HitInfo filled."""
     scene = cases.load_scene("cornell")
