@@ -107,10 +107,16 @@ constexpr int kQueues = 64, kQueueStride = 64; // stride in 32-bit words
 struct WorkQueue {
     uint32_t* tickets;
     uint32_t nUnits, chunk, nChunks;
+    // Units from *heavyUnits on (NULL: none) are known to be cheap and are handed out
+    // lightChunk at a time: a claim's round trip costs more than such a unit.
+    const uint32_t* heavyUnits;
+    uint32_t lightChunk;
 };
 struct WorkCursor {
     uint32_t queue;  // wave-uniform: the counter this wave draws from
     uint32_t ticket; // lane 0: result of the claim in flight
+    uint32_t heavyChunks, allChunks; // wave-uniform: chunks of `chunk` units, then chunks of lightChunk units
+    uint32_t heavyUnits;
 };
 RTX_DEV void claimTicket(const WorkQueue& q, WorkCursor& w)
 {
@@ -122,6 +128,11 @@ RTX_DEV void claimTicket(const WorkQueue& q, WorkCursor& w)
 RTX_DEV void openCursor(const WorkQueue& q, WorkCursor& w)
 {
     w.queue = waveIndex() % kQueues;
+    w.heavyUnits = q.nUnits;
+    if (q.heavyUnits)
+        w.heavyUnits = min(q.nUnits, __builtin_amdgcn_readfirstlane(*q.heavyUnits));
+    w.heavyChunks = (w.heavyUnits + q.chunk - 1) / q.chunk;
+    w.allChunks = w.heavyChunks + (q.nUnits - w.heavyUnits + q.lightChunk - 1) / q.lightChunk;
     claimTicket(q, w);
 }
 // Units [first, last) of the next chunk; false once every chunk has been handed out.
@@ -130,15 +141,20 @@ RTX_DEV bool nextChunk(const WorkQueue& q, WorkCursor& w, uint32_t& first, uint3
     for (;;) {
         const uint32_t k = __builtin_amdgcn_readfirstlane(w.ticket);
         const uint64_t id = uint64_t(k) * kQueues + w.queue;
-        if (id < q.nChunks) {
+        if (id < w.allChunks) {
             claimTicket(q, w);
-            first = uint32_t(id) * q.chunk;
-            last = first + min(q.chunk, q.nUnits - first);
+            if (id < w.heavyChunks) {
+                first = uint32_t(id) * q.chunk;
+                last = first + min(q.chunk, w.heavyUnits - first);
+            } else {
+                first = w.heavyUnits + (uint32_t(id) - w.heavyChunks) * q.lightChunk;
+                last = first + min(q.lightChunk, q.nUnits - first);
+            }
             return true;
         }
         const uint32_t lane = threadIdx.x & 63;
         const uint32_t seen = __hip_atomic_load(q.tickets + lane * kQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t open = __ballot(uint64_t(seen) * kQueues + lane < q.nChunks);
+        const uint64_t open = __ballot(uint64_t(seen) * kQueues + lane < w.allChunks);
         if (!open)
             return false;
         const uint32_t c = w.queue;
@@ -195,6 +211,14 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceArgs A)
 }
 
 // --------------------------------------------------------- render kernel ----
+// n / d for n < 2^31 as a multiply-high and a shift (mul == 0: d is 1); exact, and
+// scalar when n is wave-uniform.  The host picks mul = floor(2^(31+l) / d) + 1 and
+// shift = l - 1 with l = ceil(log2 d).
+struct FastDiv {
+    uint32_t mul, shift;
+};
+RTX_DEV uint32_t fastDiv(uint32_t n, FastDiv d) { return d.mul ? (__umulhi(n, d.mul) >> d.shift) : n; }
+
 struct RenderArgs {
     DScene sc;
     rtx_features f;
@@ -216,6 +240,21 @@ struct RenderArgs {
     // pixel (x, y) is jumpX[x] * jumpY[y] * jumpS[s] mod 2^31-1
     const uint32_t *jumpX, *jumpY, *jumpS;
     int32_t jumpSamples; // entries of jumpS
+    // When a unit's pixels never straddle an 8x8 block (pixelsPerUnit divides 64) the
+    // block is found from the unit number alone, with wave-uniform arithmetic:
+    // unit >> unitsPerBlockLog2 = block number in the tile sequence (-1: not so).
+    int32_t unitsPerBlockLog2;
+    uint32_t blocksPerTile, blocksPerRow;
+    FastDiv divBlocksPerTile, divTilesX, divBlocksPerRow;
+    // Pixels outside [cullX0, cullX1] x [cullY0, cullY1] (y bottom-up) cannot see the
+    // scene's bounds from this camera: a block entirely outside is black without a
+    // single ray being made (cullOn; see cullRectangle on the host side).
+    int32_t cullOn, cullX0, cullX1, cullY0, cullY1;
+    // Tiles are visited in the order tileOrder gives (position in the unit sequence ->
+    // index into this rank's tile list), longest-running first as measured on the
+    // previous frame; tileCost collects this frame's measurement.  NULL: list order.
+    const uint32_t* tileOrder;
+    uint32_t* tileCost;
 };
 
 // q-th pixel of this rank's tile sequence: tiles in rank order, 8x8 blocks
@@ -250,6 +289,51 @@ RTX_DEV float fromPreviousLaneOfRow(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
 }
+// Where lane `slot`'s pixel of `unit` is, and whether the whole unit can be skipped.
+struct PixelPlace {
+    int x, yTop;
+    uint32_t outIndex;
+    bool ok;     // the pixel exists (inside the image, inside this rank's tiles)
+    bool culled; // wave-uniform: no pixel of the unit can see the scene's bounds
+    int32_t costSlot; // wave-uniform: entry of tileCost this unit reports to, -1: none
+};
+RTX_DEV PixelPlace placePixel(const RenderArgs& A, uint32_t unit, int slot, bool laneUsed)
+{
+    PixelPlace pl;
+    pl.x = pl.yTop = 0;
+    pl.outIndex = 0;
+    pl.culled = false;
+    pl.costSlot = -1;
+    if (A.unitsPerBlockLog2 < 0) {
+        pl.ok = laneUsed && pixelOfSequence(A, unit * uint32_t(A.pixelsPerUnit) + uint32_t(slot), pl.x, pl.yTop, pl.outIndex);
+        return pl;
+    }
+    const uint32_t ts = A.tileSize;
+    const uint32_t block = unit >> A.unitsPerBlockLog2, part = unit & ((1u << A.unitsPerBlockLog2) - 1u);
+    const uint32_t position = fastDiv(block, A.divBlocksPerTile), blk = block - position * A.blocksPerTile;
+    const bool listed = position < uint32_t(A.tilesMine);
+    const uint32_t k = (A.tileOrder && listed) ? A.tileOrder[position] : position; // index into this rank's tile list
+    if (A.tileCost && listed)
+        pl.costSlot = int32_t(k);
+    const uint32_t tile = A.tileRank + k * A.tileWorld;
+    const uint32_t ty = fastDiv(tile, A.divTilesX), tx = tile - ty * uint32_t(A.tilesX);
+    const uint32_t by = fastDiv(blk, A.divBlocksPerRow), bx = blk - by * A.blocksPerRow;
+    const uint32_t x0 = tx * ts + bx * 8, y0 = ty * ts + by * 8; // block corner, rows counted from the top
+    if (A.cullOn) {
+        const int yHigh = A.H - 1 - int(y0), yLow = yHigh - 7; // the block's rows in bottom-up numbering
+        pl.culled = int(x0) + 7 < A.cullX0 || int(x0) > A.cullX1 || yHigh < A.cullY0 || yLow > A.cullY1;
+    }
+    // Morton position inside the block: de-interleave its 6 bits
+    const uint32_t m = part * uint32_t(A.pixelsPerUnit) + uint32_t(slot);
+    const uint32_t mx = (m & 1) | ((m >> 1) & 2) | ((m >> 2) & 4);
+    const uint32_t my = ((m >> 1) & 1) | ((m >> 2) & 2) | ((m >> 3) & 4);
+    pl.x = int(x0 + mx);
+    pl.yTop = int(y0 + my);
+    pl.ok = laneUsed && k < uint32_t(A.tilesMine) && pl.x < A.W && pl.yTop < A.H;
+    pl.outIndex = A.compact ? (k * ts * ts + (by * 8 + my) * ts + bx * 8 + mx) : (uint32_t(pl.yTop) * uint32_t(A.W) + uint32_t(pl.x));
+    return pl;
+}
+
 RTX_DEV float fromLane(float v, int lane) // lane: wave-uniform
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -809,9 +893,37 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
     openCursor(A.work, cursor);
     uint32_t firstUnit, lastUnit;
     while (nextChunk(A.work, cursor, firstUnit, lastUnit)) {
+        // longest unit seen per tile, reported once per chunk and tile: atomics on the
+        // small cost array all meet at a few memory channels
+        int32_t costSlot = -1;
+        uint32_t costTicks = 0;
+        auto reportCost = [&] {
+            if (costSlot >= 0 && lane == 0)
+                atomicMax(A.tileCost + costSlot, costTicks);
+        };
         for (uint32_t unit = firstUnit; unit < lastUnit; unit++) {
         V3 accum = mk(0, 0, 0);
-        uint32_t storeIndex = 0xffffffffu; // where this lane's pixel goes in the output; ~0: nowhere
+        const PixelPlace place = placePixel(A, unit, slot, laneUsed);
+        if (place.costSlot != costSlot) {
+            reportCost();
+            costSlot = place.costSlot;
+            costTicks = 1; // measured, however cheap
+        }
+        if (place.culled) {
+            // every camera ray of the unit misses the scene's bounds: the rays are
+            // counted, the pixels are black (src/render.cpp:61-64), nothing is traced
+            for (int round = 0; round < A.rounds; round++)
+                lc.countPrimary(place.ok && round * A.lanesPerPixel + sub < A.samples);
+            if (writer && place.ok) {
+                float* dst = A.out + size_t(place.outIndex) * 3;
+                dst[0] = 0.0f;
+                dst[1] = 0.0f;
+                dst[2] = 0.0f;
+            }
+            continue;
+        }
+        const uint64_t unitBegan = place.costSlot >= 0 ? wall_clock64() : 0;
+        const uint32_t storeIndex = place.ok ? place.outIndex : 0xffffffffu; // where this lane's pixel goes in the output; ~0: nowhere
         V3 carry = mk(0, 0, 0); // sum of the rounds so far (a pixel with more than 64 samples owns the wave)
         for (int round = 0; round < A.rounds; round++) {
             const int sample = round * A.lanesPerPixel + sub;
@@ -821,16 +933,13 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
             {
                 // the pixel's coordinates are only needed to make the camera ray; only the
                 // output index is kept across the traversal loops
-                int x = 0, yTop = 0;
-                uint32_t outIndex = 0;
-                const bool pixelOk = laneUsed && pixelOfSequence(A, unit * uint32_t(A.pixelsPerUnit) + uint32_t(slot), x, yTop, outIndex);
+                const int x = place.x, yTop = place.yTop;
+                const bool pixelOk = place.ok;
                 const int y = A.H - 1 - yTop; // the reference's y runs bottom-up (src/screen.cpp:37-43)
                 const uint32_t pixelIndex = uint32_t(y) * uint32_t(A.W) + uint32_t(x);
                 // pixel corner, not centre (src/render.cpp:76-79)
                 const float ndcX = float(x) / float(A.W) * 2.0f - 1.0f, ndcY = float(y) / float(A.H) * 2.0f - 1.0f;
                 active = pixelOk && sample < A.samples;
-                if (pixelOk)
-                    storeIndex = outIndex;
                 if (FULL)
                     key = sampleKey(A.seed, pixelIndex, uint32_t(sample));
                 if (active) {
@@ -937,9 +1046,58 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                 dst[2] = px.z;
             }
         }
+        // the longest unit of each tile decides how early the tile starts next frame
+        if (place.costSlot >= 0)
+            costTicks = max(costTicks, uint32_t(min(wall_clock64() - unitBegan, uint64_t(0xfffffffeu))));
         }
+        reportCost();
     }
     flushCounters<COUNT>(lc, A.stats);
+}
+
+// Tile order for the next frame: indices 0..n-1 by falling cost (ties by rising
+// index), and the costs cleared for the new measurement.  One block; the keys are
+// sorted in LDS (bitonic network), n <= kMaxOrderedTiles.
+constexpr int kMaxOrderedTiles = 8192, kOrderThreads = 1024;
+constexpr uint32_t kLightTileTicks = 500; // a tile whose longest unit took under 5 us (100 MHz ticks) is cheap
+__global__ void __launch_bounds__(kOrderThreads) orderTilesKernel(uint32_t* cost, uint32_t* order, uint32_t* heavyUnits, int n, int padded, uint32_t unitsPerTile)
+{
+    __shared__ uint64_t keys[kMaxOrderedTiles];
+    __shared__ uint32_t nHeavy;
+    if (threadIdx.x == 0)
+        nHeavy = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < padded; i += kOrderThreads) {
+        uint64_t key = 0;
+        if (i < n) {
+            const uint32_t c = cost[i] ? cost[i] : 0xffffffffu; // never measured: as if the longest
+            mine += c > kLightTileTicks;
+            key = (uint64_t(c) << 32) | uint64_t(0xffffffffu - uint32_t(i));
+        }
+        keys[i] = key;
+    }
+    atomicAdd(&nHeavy, mine);
+    __syncthreads();
+    for (int size = 2; size <= padded; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < padded / 2; t += kOrderThreads) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride), hi = lo + stride;
+                const bool descending = (lo & size) == 0;
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a < b) == descending) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += kOrderThreads) {
+        order[i] = 0xffffffffu - uint32_t(keys[i]);
+        cost[i] = 0;
+    }
+    if (threadIdx.x == 0)
+        *heavyUnits = nHeavy * unitsPerTile; // the sequence's first nHeavy tiles
 }
 
 // Batch form of getFinalColor (src/render.cpp:16-66): lane = caller-supplied ray.
@@ -1032,6 +1190,11 @@ struct DeviceCtx {
     // skip-ahead tables of the driver-level RNG, rebuilt when the frame shape changes
     uint32_t* jump = nullptr;                 // device: kJumpCap words
     int jumpW = -1, jumpH = -1, jumpS = -1, jumpD = -1;
+    // per-tile cost of the previous frame and the visiting order derived from it;
+    // valid for the frame shape / partition recorded here
+    uint32_t *tileCost = nullptr, *tileOrder = nullptr; // device: kMaxOrderedTiles words each
+    uint32_t* heavyUnits = nullptr;                       // device: one word, written by orderTilesKernel
+    int costW = -1, costH = -1, costTile = -1, costRank = -1, costWorld = -1, costDriver = -1;
 };
 constexpr size_t kTicketBytes = size_t(kQueues) * kQueueStride * sizeof(uint32_t), kStatBytes = size_t(kStatSlots) * kStatStride * sizeof(unsigned long long);
 constexpr int kJumpMaxDim = 32768, kJumpMaxSamples = 4096, kJumpCap = 2 * kJumpMaxDim + kJumpMaxSamples;
@@ -1122,6 +1285,8 @@ WorkQueue makeQueue(const DeviceCtx* c, uint32_t nUnits)
     if (const char* e = getenv("RTX_CHUNK"))
         q.chunk = uint32_t(std::max(1, atoi(e)));
     q.nChunks = uint32_t((uint64_t(nUnits) + q.chunk - 1) / q.chunk);
+    q.heavyUnits = nullptr;
+    q.lightChunk = std::max(16u, q.chunk);
     return q;
 }
 
@@ -1303,6 +1468,103 @@ int checkEnvLight(const rtx_scene* scene, const rtx_features* f, int shadowSampl
     return RTX_OK;
 }
 
+FastDiv makeFastDiv(uint32_t d)
+{
+    if (d <= 1)
+        return FastDiv { 0u, 0u };
+    uint32_t l = 0;
+    while ((1ull << l) < d)
+        l++;
+    return FastDiv { uint32_t((1ull << (31 + l)) / d + 1ull), l - 1 };
+}
+
+// Pixels that can possibly see the scene from this camera: the bounding rectangle,
+// in pixel coordinates (y bottom-up as in src/render.cpp:76-79), of the projection
+// of the root box grown by a thousandth of its size and distance (of a sphere
+// around it when a corner lies behind the camera).  A camera ray through any other
+// pixel, whatever its jitter inside the pixel, passes the true box at a distance
+// far beyond what rounding in the reference's slab test could bridge, so it misses
+// the root box there too and the pixel is black.  Returns false when no such
+// statement can be made (camera inside the bounds).
+bool cullRectangle(const rtx_scene* scene, const rtx_camera* cam, int W, int H, int32_t& x0, int32_t& x1, int32_t& y0, int32_t& y1)
+{
+    if (scene->d.rootRef == kEmptyRoot) { // nothing to hit at all
+        x0 = y0 = 1;
+        x1 = y1 = 0;
+        return true;
+    }
+    // world -> camera space: the conjugate of the camera's rotation applied to p - position
+    const double qw = cam->quat[0], qx = -cam->quat[1], qy = -cam->quat[2], qz = -cam->quat[3];
+    auto toCamera = [&](const double p[3], double out[3]) {
+        const double c[3] = { p[0] - double(cam->position[0]), p[1] - double(cam->position[1]), p[2] - double(cam->position[2]) };
+        const double ux = qy * c[2] - qz * c[1], uy = qz * c[0] - qx * c[2], uz = qx * c[1] - qy * c[0];
+        const double vx = qy * uz - qz * uy, vy = qz * ux - qx * uz, vz = qx * uy - qy * ux;
+        out[0] = c[0] + 2.0 * (qw * ux + vx), out[1] = c[1] + 2.0 * (qw * uy + vy), out[2] = c[2] + 2.0 * (qw * uz + vz);
+    };
+    double centre[3], half[3], half2 = 0, extent = 0;
+    for (int i = 0; i < 3; i++) {
+        centre[i] = 0.5 * (double(scene->d.rootLo[i]) + double(scene->d.rootHi[i]));
+        half[i] = 0.5 * (double(scene->d.rootHi[i]) - double(scene->d.rootLo[i]));
+        half2 += half[i] * half[i];
+        extent = std::max(extent, 2.0 * half[i]);
+    }
+    double cc[3];
+    toCamera(centre, cc);
+    const double dist = std::sqrt(cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2]);
+    if (!std::isfinite(dist) || !std::isfinite(half2))
+        return false;
+    // slopes x/z, y/z of the rays that can touch the bounds
+    double sLo[2] = { -INFINITY, -INFINITY }, sHi[2] = { INFINITY, INFINITY };
+    const double grow = 1e-3 * (extent + dist) + 1e-6;
+    bool inFront = true;
+    double lo2[2] = { INFINITY, INFINITY }, hi2[2] = { -INFINITY, -INFINITY };
+    for (int corner = 0; corner < 8 && inFront; corner++) {
+        double p[3], pc[3];
+        for (int i = 0; i < 3; i++)
+            p[i] = centre[i] + (((corner >> i) & 1) ? 1.0 : -1.0) * (half[i] + grow);
+        toCamera(p, pc);
+        if (!(pc[2] > 1e-3 * (extent + dist))) {
+            inFront = false;
+            break;
+        }
+        for (int a = 0; a < 2; a++) {
+            lo2[a] = std::min(lo2[a], pc[a] / pc[2]);
+            hi2[a] = std::max(hi2[a], pc[a] / pc[2]);
+        }
+    }
+    if (inFront) {
+        for (int a = 0; a < 2; a++)
+            sLo[a] = lo2[a], sHi[a] = hi2[a];
+    } else {
+        const double r = std::sqrt(half2) * 1.001 + 1e-3 * dist + 1e-6;
+        if (!(dist > r))
+            return false;
+        const double kHalfPi = 1.57079632679489661923;
+        for (int a = 0; a < 2; a++) {
+            const double d2 = std::sqrt(cc[a] * cc[a] + cc[2] * cc[2]);
+            if (!(d2 > r))
+                continue; // the sphere's shadow on this plane contains the camera: no bound on this axis
+            const double ang = std::atan2(cc[a], cc[2]), spread = std::asin(r / d2);
+            if (ang - spread >= kHalfPi || ang + spread <= -kHalfPi) { // entirely behind the camera
+                x0 = y0 = 1;
+                x1 = y1 = 0;
+                return true;
+            }
+            sLo[a] = (ang - spread <= -kHalfPi + 1e-9) ? -INFINITY : std::tan(ang - spread);
+            sHi[a] = (ang + spread >= kHalfPi - 1e-9) ? INFINITY : std::tan(ang + spread);
+        }
+    }
+    auto toPixel = [](double v) { return int32_t(std::min(std::max(v, -1e9), 1e9)); };
+    // image plane x = -ndcX * half_width, y = ndcY * half_height; pixel = (ndc + 1) / 2 * size
+    const double fx0 = (-sHi[0] / double(cam->half_width) + 1.0) * 0.5 * W, fx1 = (-sLo[0] / double(cam->half_width) + 1.0) * 0.5 * W;
+    const double fy0 = (sLo[1] / double(cam->half_height) + 1.0) * 0.5 * H, fy1 = (sHi[1] / double(cam->half_height) + 1.0) * 0.5 * H;
+    x0 = toPixel(std::floor(fx0) - 2.0);
+    x1 = toPixel(std::ceil(fx1) + 2.0);
+    y0 = toPixel(std::floor(fy0) - 2.0);
+    y1 = toPixel(std::ceil(fy1) + 2.0);
+    return true;
+}
+
 int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dOut, bool compact, rtx_stats* stats, double t0)
 {
     DeviceCtx* c = g_ctx;
@@ -1374,6 +1636,27 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         || driver == RTX_DRIVER_MOTION_BLUR; // per-sample cameras need device trigonometry
     const int mode = !full ? 0 : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : 1;
 
+    // wave-uniform block arithmetic and the culling rectangle
+    A.unitsPerBlockLog2 = -1;
+    if (64 % A.pixelsPerUnit == 0) {
+        A.unitsPerBlockLog2 = 0;
+        while ((A.pixelsPerUnit << A.unitsPerBlockLog2) < 64)
+            A.unitsPerBlockLog2++;
+    }
+    A.blocksPerRow = uint32_t(g.ts / 8);
+    A.blocksPerTile = A.blocksPerRow * A.blocksPerRow;
+    A.divBlocksPerTile = makeFastDiv(A.blocksPerTile);
+    A.divTilesX = makeFastDiv(uint32_t(g.tilesX));
+    A.divBlocksPerRow = makeFastDiv(A.blocksPerRow);
+    // One camera position for the whole frame, a miss is black, and nothing but the
+    // BVH's triangles can be hit: then blocks that cannot see the root box are skipped.
+    A.cullOn = 0;
+    A.cullX0 = A.cullY0 = 0;
+    A.cullX1 = A.cullY1 = 0;
+    if ((driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS) && !f->enable_environment_mapping && scene->d.nSpheres == 0
+        && A.unitsPerBlockLog2 >= 0 && !getenv("RTX_NO_CULL"))
+        A.cullOn = cullRectangle(scene, cam, A.W, A.H, A.cullX0, A.cullX1, A.cullY0, A.cullY1) ? 1 : 0;
+
     // skip-ahead tables for the drivers that draw from the sequential engine
     A.jumpX = c->jump;
     A.jumpY = c->jump + kJumpMaxDim;
@@ -1406,6 +1689,27 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes, c->stream));
     HIP_TRY(hipMemsetAsync(c->stats, 0, kStatBytes, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // Longest tiles first: some units (grazing shadow rays, silhouettes) run fifty times
+    // the average, and a frame is not done before the last of them, so tiles are
+    // started in the order of the longest unit each held on the previous frame of this
+    // shape.  The measurement rides along in the kernel; the order is made on the
+    // device, on the stream, with no host round trip.  The image does not depend on it.
+    A.tileOrder = nullptr;
+    A.tileCost = nullptr;
+    if (A.unitsPerBlockLog2 >= 0 && g.tilesMine > 1 && g.tilesMine <= kMaxOrderedTiles && !getenv("RTX_NO_TILE_ORDER")) {
+        if (c->costW != A.W || c->costH != A.H || c->costTile != g.ts || c->costRank != g.rank || c->costWorld != g.world || c->costDriver != driver) {
+            HIP_TRY(hipMemsetAsync(c->tileCost, 0, kMaxOrderedTiles * sizeof(uint32_t), c->stream));
+            c->costW = A.W, c->costH = A.H, c->costTile = g.ts, c->costRank = g.rank, c->costWorld = g.world, c->costDriver = driver;
+        }
+        int padded = 2;
+        while (padded < g.tilesMine)
+            padded <<= 1;
+        const uint32_t unitsPerTile = A.blocksPerTile << A.unitsPerBlockLog2;
+        hipLaunchKernelGGL(orderTilesKernel, dim3(1), dim3(kOrderThreads), 0, c->stream, c->tileCost, c->tileOrder, c->heavyUnits, g.tilesMine, padded, unitsPerTile);
+        A.tileOrder = c->tileOrder;
+        A.tileCost = c->tileCost;
+        A.work.heavyUnits = c->heavyUnits;
+    }
     if (A.work.nUnits) {
         const bool count = wantCounters();
         switch (stack) {
@@ -1525,6 +1829,9 @@ int rtx_init(int device)
         HIP_TRY(hipMalloc((void**)&c->tickets, kTicketBytes));
         HIP_TRY(hipMalloc((void**)&c->stats, kStatBytes));
         HIP_TRY(hipMalloc((void**)&c->jump, kJumpCap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->tileCost, kMaxOrderedTiles * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->tileOrder, kMaxOrderedTiles * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->heavyUnits, 256));
         c->device = device;
     }
     g_ctx = c;
