@@ -177,6 +177,31 @@ def test_shadow_query_shortcuts_do_not_change_frames(gpu_device):
         orc.close()
 
 
+@pytest.mark.parametrize("camera", [
+    dict(distance=0.2), dict(distance=0.9), dict(distance=1.3, look_at=(0.9, 0.2, 0.0)), dict(distance=3.0, look_at=(0.0, 2.5, 0.0)),
+    dict(distance=-2.0, rotation_degrees=(0, 0, 0)), dict(distance=2.0, fov_degrees=120.0), dict(distance=6.0, rotation_degrees=(80, 170, 0)),
+    dict(distance=0.7, look_at=(0.0, 0.0, 5.0)), dict(distance=30.0, fov_degrees=5.0)],
+    ids=["inside", "touching", "off-centre", "looking past", "behind", "wide", "steep", "away", "tele"])
+def test_blocks_that_cannot_see_the_scene_are_skipped_correctly(gpu_device, camera):
+    """Blocks of pixels whose camera rays cannot reach the scene's bounds are not traced.
+    The frame and the ray counts must be the oracle's for cameras inside the bounds,
+    touching them, with the scene partly or wholly outside the view, or behind."""
+    scene = cases.load_scene("monkey")
+    cam = make_camera(**camera)
+    for feat, rp in ((dict(cases.BASE), make_params(120, 72, driver=abi.DRIVER_MRAYS, samples=4)),
+                     (dict(cases.BASE, recursive=1), make_params(97, 61))):
+        f = abi.features(**feat)
+        gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+        for rep in range(2):       # the second frame runs with the tile order measured on the first
+            got = gpu.render(cam, f, rp)
+            rays_gpu = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
+        want = orc.render(cam, f, rp)
+        assert rays_gpu == tuple(int(x) for x in orc.counters[:3])
+        assert_images_close(got, want, str(camera))
+        gpu.close()
+        orc.close()
+
+
 def test_compact_tiles_and_detile_on_device(gpu_device):
     """The multi-GPU data path on one GPU: every rank's compact tile buffer
     (rtx_render_tiles_device), stacked as the gather leaves them, scattered by
