@@ -102,21 +102,26 @@ RTX_DEV void flushCounters(const LaneCounters& c, unsigned long long* stats)
 // the NEXT chunk before it starts on the current one, so the atomic's round trip
 // is hidden behind the work.  When a counter is spent the wave reads all counters
 // at once (lane i reads counter i) and moves to the next one that still has chunks.
+// A frame whose units were ordered on the device, most expensive first, is handed
+// out in three regions with chunk sizes of their own, made on the device together
+// with the order (plan = {end of region 0, 1, 2 in units, chunk of region 0, 1, 2}):
+// one unit per claim where a unit runs for a hundred microseconds, a few where the
+// claim's round trip is what a unit costs.  Units past the last region are not
+// handed out at all: they are whole 8x8 blocks that no ray can hit, which the
+// kernel's waves share out by wave number since each costs the same.
 constexpr int kQueues = 64, kQueueStride = 64; // stride in 32-bit words
+constexpr int kRegions = 3;
 
 struct WorkQueue {
     uint32_t* tickets;
     uint32_t nUnits, chunk, nChunks;
-    // Units from *heavyUnits on (NULL: none) are known to be cheap and are handed out
-    // lightChunk at a time: a claim's round trip costs more than such a unit.
-    const uint32_t* heavyUnits;
-    uint32_t lightChunk;
+    const uint32_t* plan; // device, NULL: one region of `chunk` units per claim
 };
 struct WorkCursor {
     uint32_t queue;  // wave-uniform: the counter this wave draws from
     uint32_t ticket; // lane 0: result of the claim in flight
-    uint32_t heavyChunks, allChunks; // wave-uniform: chunks of `chunk` units, then chunks of lightChunk units
-    uint32_t heavyUnits;
+    // wave-uniform: where the regions end, in units and in chunks (cumulative), and their chunk sizes
+    uint32_t endUnit[kRegions], endChunk[kRegions], chunk[kRegions];
 };
 RTX_DEV void claimTicket(const WorkQueue& q, WorkCursor& w)
 {
@@ -128,11 +133,19 @@ RTX_DEV void claimTicket(const WorkQueue& q, WorkCursor& w)
 RTX_DEV void openCursor(const WorkQueue& q, WorkCursor& w)
 {
     w.queue = waveIndex() % kQueues;
-    w.heavyUnits = q.nUnits;
-    if (q.heavyUnits)
-        w.heavyUnits = min(q.nUnits, __builtin_amdgcn_readfirstlane(*q.heavyUnits));
-    w.heavyChunks = (w.heavyUnits + q.chunk - 1) / q.chunk;
-    w.allChunks = w.heavyChunks + (q.nUnits - w.heavyUnits + q.lightChunk - 1) / q.lightChunk;
+    uint32_t unitsBefore = 0, chunksBefore = 0;
+    for (int r = 0; r < kRegions; r++) {
+        uint32_t end = q.nUnits, chunk = q.chunk;
+        if (q.plan) {
+            end = min(q.nUnits, max(unitsBefore, __builtin_amdgcn_readfirstlane(q.plan[r])));
+            chunk = max(1u, __builtin_amdgcn_readfirstlane(q.plan[kRegions + r]));
+        }
+        chunksBefore += (end - unitsBefore + chunk - 1) / chunk;
+        unitsBefore = end;
+        w.endUnit[r] = end;
+        w.endChunk[r] = chunksBefore;
+        w.chunk[r] = chunk;
+    }
     claimTicket(q, w);
 }
 // Units [first, last) of the next chunk; false once every chunk has been handed out.
@@ -141,20 +154,24 @@ RTX_DEV bool nextChunk(const WorkQueue& q, WorkCursor& w, uint32_t& first, uint3
     for (;;) {
         const uint32_t k = __builtin_amdgcn_readfirstlane(w.ticket);
         const uint64_t id = uint64_t(k) * kQueues + w.queue;
-        if (id < w.allChunks) {
+        if (id < w.endChunk[kRegions - 1]) {
             claimTicket(q, w);
-            if (id < w.heavyChunks) {
-                first = uint32_t(id) * q.chunk;
-                last = first + min(q.chunk, w.heavyUnits - first);
+            const uint32_t c = uint32_t(id);
+            if (c < w.endChunk[0]) {
+                first = c * w.chunk[0];
+                last = min(first + w.chunk[0], w.endUnit[0]);
+            } else if (c < w.endChunk[1]) {
+                first = w.endUnit[0] + (c - w.endChunk[0]) * w.chunk[1];
+                last = min(first + w.chunk[1], w.endUnit[1]);
             } else {
-                first = w.heavyUnits + (uint32_t(id) - w.heavyChunks) * q.lightChunk;
-                last = first + min(q.lightChunk, q.nUnits - first);
+                first = w.endUnit[1] + (c - w.endChunk[1]) * w.chunk[2];
+                last = min(first + w.chunk[2], w.endUnit[2]);
             }
             return true;
         }
         const uint32_t lane = threadIdx.x & 63;
         const uint32_t seen = __hip_atomic_load(q.tickets + lane * kQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t open = __ballot(uint64_t(seen) * kQueues + lane < w.allChunks);
+        const uint64_t open = __ballot(uint64_t(seen) * kQueues + lane < w.endChunk[kRegions - 1]);
         if (!open)
             return false;
         const uint32_t c = w.queue;
@@ -250,12 +267,20 @@ struct RenderArgs {
     // scene's bounds from this camera: a block entirely outside is black without a
     // single ray being made (cullOn; see cullRectangle on the host side).
     int32_t cullOn, cullX0, cullX1, cullY0, cullY1;
-    // Tiles are visited in the order tileOrder gives (position in the unit sequence ->
-    // index into this rank's tile list), longest-running first as measured on the
-    // previous frame; tileCost collects this frame's measurement.  NULL: list order.
-    const uint32_t* tileOrder;
-    uint32_t* tileCost;
+    // 8x8 blocks are visited in the order blockOrder gives (position in the unit
+    // sequence -> index into this rank's blocks, tile after tile), longest-running
+    // first as measured on the previous frame; blockCost collects this frame's
+    // measurement.  NULL: list order.
+    const uint32_t* blockOrder;
+    uint32_t* blockCost;
+    uint32_t blocksMine; // tilesMine * blocksPerTile
+    // Block i reports to blockCost[costIndex(A, i)]: blocks that are neighbours in the
+    // list, and so in time, are costStride words apart, since atomics on one 256-byte
+    // line all queue at one memory channel.  A unit shorter than costFloor ticks does
+    // not report at all: the order kernel has already entered its block as cheap.
+    uint32_t costStride, costFloor;
 };
+RTX_DEV uint32_t costIndex(const RenderArgs& A, uint32_t block) { return (block & 63u) * A.costStride + (block >> 6); }
 
 // q-th pixel of this rank's tile sequence: tiles in rank order, 8x8 blocks
 // row-major inside a tile, Morton order inside a block.  Returns false for
@@ -295,8 +320,44 @@ struct PixelPlace {
     uint32_t outIndex;
     bool ok;     // the pixel exists (inside the image, inside this rank's tiles)
     bool culled; // wave-uniform: no pixel of the unit can see the scene's bounds
-    int32_t costSlot; // wave-uniform: entry of tileCost this unit reports to, -1: none
+    int32_t costSlot; // wave-uniform: entry of blockCost this unit reports to, -1: none
 };
+// The 8x8 block with number `block` in the unit sequence (all wave-uniform)
+struct BlockPlace {
+    uint32_t own;     // index into this rank's blocks
+    uint32_t k;       // index into this rank's tile list
+    uint32_t x0, y0;  // block corner in the image, rows counted from the top
+    uint32_t bx, by;  // block position inside its tile
+    bool listed;      // the tile exists
+    bool culled;      // no pixel of the block can see the scene's bounds
+};
+RTX_DEV BlockPlace placeBlock(const RenderArgs& A, uint32_t block)
+{
+    BlockPlace b;
+    const uint32_t ts = A.tileSize;
+    b.listed = block < A.blocksMine;
+    b.own = (A.blockOrder && b.listed) ? A.blockOrder[block] : block;
+    b.k = fastDiv(b.own, A.divBlocksPerTile);
+    const uint32_t blk = b.own - b.k * A.blocksPerTile;
+    const uint32_t tile = A.tileRank + b.k * A.tileWorld;
+    const uint32_t ty = fastDiv(tile, A.divTilesX), tx = tile - ty * uint32_t(A.tilesX);
+    b.by = fastDiv(blk, A.divBlocksPerRow);
+    b.bx = blk - b.by * A.blocksPerRow;
+    b.x0 = tx * ts + b.bx * 8;
+    b.y0 = ty * ts + b.by * 8;
+    b.culled = false;
+    if (A.cullOn) {
+        const int yHigh = A.H - 1 - int(b.y0), yLow = yHigh - 7; // the block's rows in bottom-up numbering
+        b.culled = int(b.x0) + 7 < A.cullX0 || int(b.x0) > A.cullX1 || yHigh < A.cullY0 || yLow > A.cullY1;
+    }
+    return b;
+}
+RTX_DEV uint32_t blockPixelIndex(const RenderArgs& A, const BlockPlace& b, uint32_t mx, uint32_t my)
+{
+    const uint32_t ts = A.tileSize;
+    return A.compact ? (b.k * ts * ts + (b.by * 8 + my) * ts + b.bx * 8 + mx) : ((b.y0 + my) * uint32_t(A.W) + b.x0 + mx);
+}
+
 RTX_DEV PixelPlace placePixel(const RenderArgs& A, uint32_t unit, int slot, bool laneUsed)
 {
     PixelPlace pl;
@@ -308,29 +369,19 @@ RTX_DEV PixelPlace placePixel(const RenderArgs& A, uint32_t unit, int slot, bool
         pl.ok = laneUsed && pixelOfSequence(A, unit * uint32_t(A.pixelsPerUnit) + uint32_t(slot), pl.x, pl.yTop, pl.outIndex);
         return pl;
     }
-    const uint32_t ts = A.tileSize;
-    const uint32_t block = unit >> A.unitsPerBlockLog2, part = unit & ((1u << A.unitsPerBlockLog2) - 1u);
-    const uint32_t position = fastDiv(block, A.divBlocksPerTile), blk = block - position * A.blocksPerTile;
-    const bool listed = position < uint32_t(A.tilesMine);
-    const uint32_t k = (A.tileOrder && listed) ? A.tileOrder[position] : position; // index into this rank's tile list
-    if (A.tileCost && listed)
-        pl.costSlot = int32_t(k);
-    const uint32_t tile = A.tileRank + k * A.tileWorld;
-    const uint32_t ty = fastDiv(tile, A.divTilesX), tx = tile - ty * uint32_t(A.tilesX);
-    const uint32_t by = fastDiv(blk, A.divBlocksPerRow), bx = blk - by * A.blocksPerRow;
-    const uint32_t x0 = tx * ts + bx * 8, y0 = ty * ts + by * 8; // block corner, rows counted from the top
-    if (A.cullOn) {
-        const int yHigh = A.H - 1 - int(y0), yLow = yHigh - 7; // the block's rows in bottom-up numbering
-        pl.culled = int(x0) + 7 < A.cullX0 || int(x0) > A.cullX1 || yHigh < A.cullY0 || yLow > A.cullY1;
-    }
+    const uint32_t part = unit & ((1u << A.unitsPerBlockLog2) - 1u);
+    const BlockPlace b = placeBlock(A, unit >> A.unitsPerBlockLog2);
+    if (A.blockCost && b.listed)
+        pl.costSlot = int32_t(b.own);
+    pl.culled = b.culled;
     // Morton position inside the block: de-interleave its 6 bits
     const uint32_t m = part * uint32_t(A.pixelsPerUnit) + uint32_t(slot);
     const uint32_t mx = (m & 1) | ((m >> 1) & 2) | ((m >> 2) & 4);
     const uint32_t my = ((m >> 1) & 1) | ((m >> 2) & 2) | ((m >> 3) & 4);
-    pl.x = int(x0 + mx);
-    pl.yTop = int(y0 + my);
-    pl.ok = laneUsed && k < uint32_t(A.tilesMine) && pl.x < A.W && pl.yTop < A.H;
-    pl.outIndex = A.compact ? (k * ts * ts + (by * 8 + my) * ts + bx * 8 + mx) : (uint32_t(pl.yTop) * uint32_t(A.W) + uint32_t(pl.x));
+    pl.x = int(b.x0 + mx);
+    pl.yTop = int(b.y0 + my);
+    pl.ok = laneUsed && b.listed && pl.x < A.W && pl.yTop < A.H;
+    pl.outIndex = blockPixelIndex(A, b, mx, my);
     return pl;
 }
 
@@ -889,19 +940,49 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
     // the lane that ends up holding its pixel's sum and stores it
     const bool writer = laneUsed && sub == A.lanesPerPixel - 1;
 
+    // An 8x8 block that cannot see the scene: every camera ray misses the scene's
+    // bounds, so the rays are counted, the pixels are black (src/render.cpp:61-64) and
+    // nothing is traced.  One wave-wide store, lane = pixel.
+    auto blackBlock = [&](const BlockPlace& b) {
+        const uint32_t mx = uint32_t(lane) & 7u, my = uint32_t(lane) >> 3;
+        const bool ok = b.listed && int(b.x0 + mx) < A.W && int(b.y0 + my) < A.H;
+        lc.primary += uint32_t(__popcll(__ballot(ok))) * uint32_t(A.samples);
+        if (ok) {
+            float* dst = A.out + size_t(blockPixelIndex(A, b, mx, my)) * 3;
+            dst[0] = 0.0f;
+            dst[1] = 0.0f;
+            dst[2] = 0.0f;
+        }
+    };
     WorkCursor cursor;
     openCursor(A.work, cursor);
     uint32_t firstUnit, lastUnit;
     while (nextChunk(A.work, cursor, firstUnit, lastUnit)) {
-        // longest unit seen per tile, reported once per chunk and tile: atomics on the
-        // small cost array all meet at a few memory channels
+        // longest unit seen per block, reported once per chunk and block
         int32_t costSlot = -1;
         uint32_t costTicks = 0;
         auto reportCost = [&] {
-            if (costSlot >= 0 && lane == 0)
-                atomicMax(A.tileCost + costSlot, costTicks);
+            if (costSlot >= 0 && lane == 0 && costTicks >= A.costFloor)
+                atomicMax(A.blockCost + costIndex(A, uint32_t(costSlot)), costTicks);
         };
+        // (chunks shorter than a block: expensive or cheap units, not empty blocks)
+        const bool mayHoldBlocks = A.cullOn && A.unitsPerBlockLog2 >= 0 && lastUnit - firstUnit >= (1u << A.unitsPerBlockLog2);
         for (uint32_t unit = firstUnit; unit < lastUnit; unit++) {
+        // a whole 8x8 block inside this chunk that cannot see the scene: one wave-wide
+        // store of black pixels (lane = pixel) instead of its units one by one
+        if (mayHoldBlocks && (unit & ((1u << A.unitsPerBlockLog2) - 1u)) == 0 && unit + (1u << A.unitsPerBlockLog2) <= lastUnit) {
+            const BlockPlace b = placeBlock(A, unit >> A.unitsPerBlockLog2);
+            if (b.culled) {
+                blackBlock(b);
+                if (A.blockCost && b.listed && int32_t(b.own) != costSlot) {
+                    reportCost();
+                    costSlot = int32_t(b.own);
+                    costTicks = 1;
+                }
+                unit += (1u << A.unitsPerBlockLog2) - 1u;
+                continue;
+            }
+        }
         V3 accum = mk(0, 0, 0);
         const PixelPlace place = placePixel(A, unit, slot, laneUsed);
         if (place.costSlot != costSlot) {
@@ -1046,58 +1127,98 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                 dst[2] = px.z;
             }
         }
-        // the longest unit of each tile decides how early the tile starts next frame
+        // the longest unit of each block decides how early the block starts next frame
         if (place.costSlot >= 0)
             costTicks = max(costTicks, uint32_t(min(wall_clock64() - unitBegan, uint64_t(0xfffffffeu))));
         }
         reportCost();
     }
+    if (A.work.plan) {
+        // the ordered sequence ends with the blocks that cannot see the scene
+        const uint32_t nWaves = gridDim.x * (kBlock / 64);
+        for (uint32_t block = (cursor.endUnit[kRegions - 1] >> A.unitsPerBlockLog2) + waveIndex(); block < A.blocksMine; block += nWaves)
+            blackBlock(placeBlock(A, block));
+    }
     flushCounters<COUNT>(lc, A.stats);
 }
 
-// Tile order for the next frame: indices 0..n-1 by falling cost (ties by rising
-// index), and the costs cleared for the new measurement.  One block; the keys are
-// sorted in LDS (bitonic network), n <= kMaxOrderedTiles.
-constexpr int kMaxOrderedTiles = 8192, kOrderThreads = 1024;
-constexpr uint32_t kLightTileTicks = 500; // a tile whose longest unit took under 5 us (100 MHz ticks) is cheap
-__global__ void __launch_bounds__(kOrderThreads) orderTilesKernel(uint32_t* cost, uint32_t* order, uint32_t* heavyUnits, int n, int padded, uint32_t unitsPerTile)
+// Block order for this frame: the rank's blocks that can see the scene by falling
+// cost class (the longest unit each held on the previous frame, in half octaves;
+// never measured counts as the most expensive), then the blocks that cannot.
+// Inside a class the blocks keep their list order, so neighbours on the screen with
+// like costs stay neighbours in the sequence and the waves working side by side
+// keep touching the same part of the scene.  The work queue's plan comes with it:
+// region 0 = the blocks up to class kLastSingleClass, one unit per claim; region 1 =
+// up to kLastHeavyClass, one to three units per claim depending on how many units
+// each wave will get; region 2 = the rest of the blocks that can see the scene, four.
+// The costs are reset for the new measurement: 1 (cheap until a unit reports
+// otherwise) for a block that can see the scene, 0 (never measured) for the others.
+// One workgroup: a stable counting sort, thread t owning a run of consecutive blocks.
+constexpr int kMaxOrderedBlocks = 1 << 20, kOrderThreads = 256, kCostClasses = 32;
+// costs are in ticks of the 100 MHz wall clock; class 15 starts at 232 us, class 23 at 14.5 us
+constexpr uint32_t kLastSingleClass = 15, kLastHeavyClass = 23, kEmptyClass = kCostClasses - 1;
+constexpr uint32_t kCostFloorTicks = 256; // 2.5 us: well inside the cheapest classes
+RTX_DEV uint32_t costClass(uint32_t c) // 0 = most expensive ... 30 = cheapest
 {
-    __shared__ uint64_t keys[kMaxOrderedTiles];
-    __shared__ uint32_t nHeavy;
-    if (threadIdx.x == 0)
-        nHeavy = 0;
+    if (c == 0)
+        return 0;
+    const uint32_t msb = 31u - uint32_t(__clz(int(c)));
+    const uint32_t level = 2 * msb + (msb ? (c >> (msb - 1)) & 1u : 0u); // half octaves; 18 = 5.12 us
+    if (level >= 18)
+        return level >= 44 ? 0 : 44 - level; // 1 .. 26
+    return level >= 16 ? 27 : level >= 14 ? 28 : level >= 10 ? 29 : 30;
+}
+__global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(RenderArgs A, uint32_t* order, uint32_t* plan, uint32_t nWaves, uint32_t lastSingleClass, uint32_t lastHeavyClass)
+{
+    // count[c][t]: blocks of class c in thread t's run; after the scan, where they go
+    __shared__ uint32_t count[kCostClasses][kOrderThreads], partial[kOrderThreads];
+    uint32_t* cost = A.blockCost;
+    const uint32_t n = A.blocksMine;
+    const uint32_t t = threadIdx.x;
+    for (int c = 0; c < kCostClasses; c++)
+        count[c][t] = 0;
+    // (A.blockOrder is NULL here: placeBlock answers for list order)
+    const uint32_t per = (n + kOrderThreads - 1) / kOrderThreads, lo = min(n, t * per), hi = min(n, lo + per);
+    for (uint32_t i = lo; i < hi; i++)
+        count[placeBlock(A, i).culled ? kEmptyClass : costClass(cost[costIndex(A, i)])][t]++;
     __syncthreads();
-    uint32_t mine = 0;
-    for (int i = threadIdx.x; i < padded; i += kOrderThreads) {
-        uint64_t key = 0;
-        if (i < n) {
-            const uint32_t c = cost[i] ? cost[i] : 0xffffffffu; // never measured: as if the longest
-            mine += c > kLightTileTicks;
-            key = (uint64_t(c) << 32) | uint64_t(0xffffffffu - uint32_t(i));
-        }
-        keys[i] = key;
-    }
-    atomicAdd(&nHeavy, mine);
+    // exclusive prefix sum over count[][] read as one array, class after class: each
+    // thread sums kCostClasses consecutive entries, the sums are scanned, then spread
+    uint32_t* flat = &count[0][0];
+    uint32_t sum = 0;
+    for (int j = 0; j < kCostClasses; j++)
+        sum += flat[t * kCostClasses + j];
+    partial[t] = sum;
     __syncthreads();
-    for (int size = 2; size <= padded; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < padded / 2; t += kOrderThreads) {
-                const int lo = ((t / stride) * stride * 2) + (t % stride), hi = lo + stride;
-                const bool descending = (lo & size) == 0;
-                const uint64_t a = keys[lo], b = keys[hi];
-                if ((a < b) == descending) {
-                    keys[lo] = b;
-                    keys[hi] = a;
-                }
-            }
-            __syncthreads();
-        }
-    for (int i = threadIdx.x; i < n; i += kOrderThreads) {
-        order[i] = 0xffffffffu - uint32_t(keys[i]);
-        cost[i] = 0;
+    for (uint32_t step = 1; step < kOrderThreads; step <<= 1) {
+        const uint32_t add = t >= step ? partial[t - step] : 0;
+        __syncthreads();
+        partial[t] += add;
+        __syncthreads();
     }
-    if (threadIdx.x == 0)
-        *heavyUnits = nHeavy * unitsPerTile; // the sequence's first nHeavy tiles
+    uint32_t at = partial[t] - sum;
+    for (int j = 0; j < kCostClasses; j++) {
+        const uint32_t v = flat[t * kCostClasses + j];
+        flat[t * kCostClasses + j] = at;
+        at += v;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t end0 = count[lastSingleClass + 1][0] << A.unitsPerBlockLog2, end1 = count[lastHeavyClass + 1][0] << A.unitsPerBlockLog2;
+        plan[0] = end0;
+        plan[1] = end1;
+        plan[2] = count[kEmptyClass][0] << A.unitsPerBlockLog2;
+        plan[3] = 1;
+        plan[4] = min(3u, max(1u, (end1 - end0) / (nWaves * 32u)));
+        plan[5] = 4;
+    }
+    __syncthreads();
+    for (uint32_t i = lo; i < hi; i++) {
+        const bool empty = placeBlock(A, i).culled;
+        uint32_t& mine = cost[costIndex(A, i)];
+        order[count[empty ? kEmptyClass : costClass(mine)][t]++] = i;
+        mine = empty ? 0u : 1u;
+    }
 }
 
 // Batch form of getFinalColor (src/render.cpp:16-66): lane = caller-supplied ray.
@@ -1192,8 +1313,8 @@ struct DeviceCtx {
     int jumpW = -1, jumpH = -1, jumpS = -1, jumpD = -1;
     // per-tile cost of the previous frame and the visiting order derived from it;
     // valid for the frame shape / partition recorded here
-    uint32_t *tileCost = nullptr, *tileOrder = nullptr; // device: kMaxOrderedTiles words each
-    uint32_t* heavyUnits = nullptr;                       // device: one word, written by orderTilesKernel
+    uint32_t *blockCost = nullptr, *blockOrder = nullptr; // device: kMaxOrderedBlocks words each
+    uint32_t* queueBounds = nullptr;                      // device: the work queue's plan, written by orderBlocksKernel
     int costW = -1, costH = -1, costTile = -1, costRank = -1, costWorld = -1, costDriver = -1;
 };
 constexpr size_t kTicketBytes = size_t(kQueues) * kQueueStride * sizeof(uint32_t), kStatBytes = size_t(kStatSlots) * kStatStride * sizeof(unsigned long long);
@@ -1285,8 +1406,7 @@ WorkQueue makeQueue(const DeviceCtx* c, uint32_t nUnits)
     if (const char* e = getenv("RTX_CHUNK"))
         q.chunk = uint32_t(std::max(1, atoi(e)));
     q.nChunks = uint32_t((uint64_t(nUnits) + q.chunk - 1) / q.chunk);
-    q.heavyUnits = nullptr;
-    q.lightChunk = std::max(16u, q.chunk);
+    q.plan = nullptr;
     return q;
 }
 
@@ -1689,26 +1809,31 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes, c->stream));
     HIP_TRY(hipMemsetAsync(c->stats, 0, kStatBytes, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    // Longest tiles first: some units (grazing shadow rays, silhouettes) run fifty times
-    // the average, and a frame is not done before the last of them, so tiles are
-    // started in the order of the longest unit each held on the previous frame of this
-    // shape.  The measurement rides along in the kernel; the order is made on the
+    // Longest blocks first: some units (grazing shadow rays, silhouettes) run fifty times
+    // the average, and a frame is not done before the last of them, so the 8x8 blocks
+    // are started in the order of the longest unit each held on the previous frame of
+    // this shape.  The measurement rides along in the kernel; the order is made on the
     // device, on the stream, with no host round trip.  The image does not depend on it.
-    A.tileOrder = nullptr;
-    A.tileCost = nullptr;
-    if (A.unitsPerBlockLog2 >= 0 && g.tilesMine > 1 && g.tilesMine <= kMaxOrderedTiles && !getenv("RTX_NO_TILE_ORDER")) {
+    A.blockOrder = nullptr;
+    A.blockCost = nullptr;
+    A.blocksMine = uint32_t(g.tilesMine) * A.blocksPerTile;
+    A.costStride = (A.blocksMine + 63u) / 64u;
+    A.costFloor = 0;
+    if (A.unitsPerBlockLog2 >= 0 && A.blocksMine > 1 && A.blocksMine <= uint32_t(kMaxOrderedBlocks) && !getenv("RTX_NO_TILE_ORDER")) {
+        A.blockCost = c->blockCost;
         if (c->costW != A.W || c->costH != A.H || c->costTile != g.ts || c->costRank != g.rank || c->costWorld != g.world || c->costDriver != driver) {
-            HIP_TRY(hipMemsetAsync(c->tileCost, 0, kMaxOrderedTiles * sizeof(uint32_t), c->stream));
+            // nothing measured yet for frames of this shape: this one runs in list order
+            HIP_TRY(hipMemsetAsync(c->blockCost, 0, size_t(A.costStride) * 64 * sizeof(uint32_t), c->stream));
             c->costW = A.W, c->costH = A.H, c->costTile = g.ts, c->costRank = g.rank, c->costWorld = g.world, c->costDriver = driver;
+        } else {
+            auto envClass = [](const char* name, uint32_t fallback) { const char* e = getenv(name); return e ? uint32_t(atoi(e)) : fallback; };
+            hipLaunchKernelGGL(orderBlocksKernel, dim3(1), dim3(kOrderThreads), 0, c->stream, A, c->blockOrder, c->queueBounds, uint32_t(c->numCUs) * 16u,
+                envClass("RTX_SINGLE_CLASS", kLastSingleClass), envClass("RTX_HEAVY_CLASS", kLastHeavyClass));
+            A.blockOrder = c->blockOrder;
+            A.costFloor = kCostFloorTicks;
+            A.work.plan = c->queueBounds;
+            A.work.nChunks = A.work.nUnits; // (for the grid size: at most)
         }
-        int padded = 2;
-        while (padded < g.tilesMine)
-            padded <<= 1;
-        const uint32_t unitsPerTile = A.blocksPerTile << A.unitsPerBlockLog2;
-        hipLaunchKernelGGL(orderTilesKernel, dim3(1), dim3(kOrderThreads), 0, c->stream, c->tileCost, c->tileOrder, c->heavyUnits, g.tilesMine, padded, unitsPerTile);
-        A.tileOrder = c->tileOrder;
-        A.tileCost = c->tileCost;
-        A.work.heavyUnits = c->heavyUnits;
     }
     if (A.work.nUnits) {
         const bool count = wantCounters();
@@ -1829,9 +1954,9 @@ int rtx_init(int device)
         HIP_TRY(hipMalloc((void**)&c->tickets, kTicketBytes));
         HIP_TRY(hipMalloc((void**)&c->stats, kStatBytes));
         HIP_TRY(hipMalloc((void**)&c->jump, kJumpCap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->tileCost, kMaxOrderedTiles * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->tileOrder, kMaxOrderedTiles * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->heavyUnits, 256));
+        HIP_TRY(hipMalloc((void**)&c->blockCost, (kMaxOrderedBlocks + 64) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->blockOrder, kMaxOrderedBlocks * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->queueBounds, 256));
         c->device = device;
     }
     g_ctx = c;

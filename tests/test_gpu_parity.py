@@ -192,12 +192,14 @@ def test_blocks_that_cannot_see_the_scene_are_skipped_correctly(gpu_device, came
                      (dict(cases.BASE, recursive=1), make_params(97, 61))):
         f = abi.features(**feat)
         gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
-        for rep in range(2):       # the second frame runs with the tile order measured on the first
+        want = orc.render(cam, f, rp)
+        # the first frame of a shape runs in list order, the next ones longest blocks
+        # first as measured on the frame before (here possibly with another camera)
+        for rep in range(3):
             got = gpu.render(cam, f, rp)
             rays_gpu = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
-        want = orc.render(cam, f, rp)
-        assert rays_gpu == tuple(int(x) for x in orc.counters[:3])
-        assert_images_close(got, want, str(camera))
+            assert rays_gpu == tuple(int(x) for x in orc.counters[:3]), (camera, rep)
+            assert_images_close(got, want, "%s frame %d" % (camera, rep))
         gpu.close()
         orc.close()
 
@@ -417,8 +419,17 @@ def test_dragon_standin_full_size_properties(gpu_device):
     assert s.rays_primary == 1920 * 1080 * 16
     assert s.rays_shadow == s.shaded_hits and s.rays_bounce == 0
     assert 0 < s.rays_shadow < s.rays_primary
-    b = gpu.render(cam, f, rp)
-    assert np.array_equal(a, b), "two renders of the same frame differ"
+    first = (s.rays_primary, s.rays_shadow, s.shaded_hits)
+    # later frames run their blocks in the order measured on the frame before
+    for rep in range(3):
+        b = gpu.render(cam, f, rp)
+        assert np.array_equal(a, b), "renders of the same frame differ (frame %d)" % (rep + 1)
+        t = gpu.stats
+        assert (t.rays_primary, t.rays_shadow, t.shaded_hits) == first
+    moved = make_camera(rotation_degrees=(35, -50, 0), distance=2.2)  # stale measurements must not matter
+    c1 = gpu.render(moved, f, rp)
+    c2 = gpu.render(moved, f, rp)
+    assert np.array_equal(c1, c2) and not np.array_equal(a, c1)
     assert np.isfinite(a).all() and a.min() >= 0.0
     # the same scene at a size the oracle finishes quickly
     small = make_params(96, 54, driver=abi.DRIVER_MRAYS, samples=16)
