@@ -1151,10 +1151,12 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
 // region 0 = the blocks up to class kLastSingleClass, one unit per claim; region 1 =
 // up to kLastHeavyClass, one to three units per claim depending on how many units
 // each wave will get; region 2 = the rest of the blocks that can see the scene, four.
-// The costs are reset for the new measurement: 1 (cheap until a unit reports
-// otherwise) for a block that can see the scene, 0 (never measured) for the others.
-// One workgroup: a stable counting sort, thread t owning a run of consecutive blocks.
-constexpr int kMaxOrderedBlocks = 1 << 20, kOrderThreads = 256, kCostClasses = 32;
+// Two kernels: classifyBlocksKernel (one thread per block) finds each block's class
+// and resets its cost for the new measurement: 1 (cheap until a unit reports
+// otherwise) for a block that can see the scene, 0 (never measured) for the others;
+// orderBlocksKernel (one workgroup) is a stable counting sort on the classes, each
+// wave owning a run of consecutive blocks.
+constexpr int kMaxOrderedBlocks = 1 << 20, kOrderThreads = 1024, kOrderWaves = kOrderThreads / 64, kCostClasses = 32;
 // costs are in ticks of the 100 MHz wall clock; class 15 starts at 232 us, class 23 at 14.5 us
 constexpr uint32_t kLastSingleClass = 15, kLastHeavyClass = 23, kEmptyClass = kCostClasses - 1;
 constexpr uint32_t kCostFloorTicks = 256; // 2.5 us: well inside the cheapest classes
@@ -1168,57 +1170,85 @@ RTX_DEV uint32_t costClass(uint32_t c) // 0 = most expensive ... 30 = cheapest
         return level >= 44 ? 0 : 44 - level; // 1 .. 26
     return level >= 16 ? 27 : level >= 14 ? 28 : level >= 10 ? 29 : 30;
 }
-__global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(RenderArgs A, uint32_t* order, uint32_t* plan, uint32_t nWaves, uint32_t lastSingleClass, uint32_t lastHeavyClass)
+__global__ void __launch_bounds__(256) classifyBlocksKernel(RenderArgs A, uint8_t* classes)
 {
-    // count[c][t]: blocks of class c in thread t's run; after the scan, where they go
-    __shared__ uint32_t count[kCostClasses][kOrderThreads], partial[kOrderThreads];
-    uint32_t* cost = A.blockCost;
-    const uint32_t n = A.blocksMine;
-    const uint32_t t = threadIdx.x;
-    for (int c = 0; c < kCostClasses; c++)
-        count[c][t] = 0;
-    // (A.blockOrder is NULL here: placeBlock answers for list order)
-    const uint32_t per = (n + kOrderThreads - 1) / kOrderThreads, lo = min(n, t * per), hi = min(n, lo + per);
-    for (uint32_t i = lo; i < hi; i++)
-        count[placeBlock(A, i).culled ? kEmptyClass : costClass(cost[costIndex(A, i)])][t]++;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= A.blocksMine)
+        return;
+    const bool empty = placeBlock(A, i).culled; // (A.blockOrder is NULL here: list order)
+    uint32_t& mine = A.blockCost[costIndex(A, i)];
+    classes[i] = uint8_t(empty ? kEmptyClass : costClass(mine));
+    mine = empty ? 0u : 1u;
+}
+__global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(const uint8_t* classes, uint32_t n, int unitsPerBlockLog2, uint32_t* order, uint32_t* plan, uint32_t nWaves, uint32_t lastSingleClass,
+                                                                    uint32_t lastHeavyClass)
+{
+    // table[c][w]: blocks of class c in wave w's run; after the scan, where they go
+    __shared__ uint32_t table[kCostClasses * kOrderWaves];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t per = ((n + kOrderWaves * 64u - 1u) / (kOrderWaves * 64u)) * 64u, lo = min(n, wave * per), hi = min(n, lo + per);
+    // One step takes 64 consecutive blocks, lane = block, and visits the classes among
+    // them one after another (neighbouring blocks share few).  `slots` holds one number
+    // per class in lanes 0..31: the count so far (first pass), the next place (second).
+    uint32_t slots = 0;
+    // (kAhead steps' classes are read together: the reads' latency is what a step costs)
+    constexpr uint32_t kAhead = 8;
+    auto sweep = [&](bool place) {
+        for (uint32_t group = lo; group < hi; group += 64u * kAhead) {
+            uint32_t ahead[kAhead];
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; j++) {
+                const uint32_t i = group + j * 64u + lane;
+                ahead[j] = i < hi ? classes[i] : 0xffu;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; j++) {
+                const uint32_t i = group + j * 64u + lane, cls = ahead[j];
+                uint64_t rest = __ballot(i < hi);
+                while (rest) {
+                    const uint32_t b = uint32_t(__builtin_amdgcn_readlane(int(cls), __builtin_ctzll(rest)));
+                    const uint64_t same = __ballot(cls == b);
+                    if (place && cls == b) {
+                        const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(same >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(same), 0u));
+                        order[uint32_t(__builtin_amdgcn_readlane(int(slots), int(b))) + before] = i;
+                    }
+                    slots += lane == b ? uint32_t(__popcll(same)) : 0u;
+                    rest &= ~same;
+                }
+            }
+        }
+    };
+    sweep(false);
+    if (lane < kCostClasses)
+        table[lane * kOrderWaves + wave] = slots;
     __syncthreads();
-    // exclusive prefix sum over count[][] read as one array, class after class: each
-    // thread sums kCostClasses consecutive entries, the sums are scanned, then spread
-    uint32_t* flat = &count[0][0];
-    uint32_t sum = 0;
-    for (int j = 0; j < kCostClasses; j++)
-        sum += flat[t * kCostClasses + j];
-    partial[t] = sum;
-    __syncthreads();
-    for (uint32_t step = 1; step < kOrderThreads; step <<= 1) {
-        const uint32_t add = t >= step ? partial[t - step] : 0;
+    // exclusive prefix sum over the table, class after class
+    const uint32_t e = threadIdx.x;
+    const bool entry = e < kCostClasses * kOrderWaves;
+    const uint32_t mine = entry ? table[e] : 0u;
+    for (uint32_t step = 1; step < kCostClasses * kOrderWaves; step <<= 1) {
+        const uint32_t add = (entry && e >= step) ? table[e - step] : 0u;
         __syncthreads();
-        partial[t] += add;
+        if (entry)
+            table[e] += add;
         __syncthreads();
     }
-    uint32_t at = partial[t] - sum;
-    for (int j = 0; j < kCostClasses; j++) {
-        const uint32_t v = flat[t * kCostClasses + j];
-        flat[t * kCostClasses + j] = at;
-        at += v;
-    }
+    const uint32_t before = entry ? table[e] - mine : 0u;
     __syncthreads();
-    if (t == 0) {
-        const uint32_t end0 = count[lastSingleClass + 1][0] << A.unitsPerBlockLog2, end1 = count[lastHeavyClass + 1][0] << A.unitsPerBlockLog2;
+    if (entry)
+        table[e] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t end0 = table[(lastSingleClass + 1) * kOrderWaves] << unitsPerBlockLog2, end1 = table[(lastHeavyClass + 1) * kOrderWaves] << unitsPerBlockLog2;
         plan[0] = end0;
         plan[1] = end1;
-        plan[2] = count[kEmptyClass][0] << A.unitsPerBlockLog2;
+        plan[2] = table[kEmptyClass * kOrderWaves] << unitsPerBlockLog2;
         plan[3] = 1;
         plan[4] = min(3u, max(1u, (end1 - end0) / (nWaves * 32u)));
         plan[5] = 4;
     }
-    __syncthreads();
-    for (uint32_t i = lo; i < hi; i++) {
-        const bool empty = placeBlock(A, i).culled;
-        uint32_t& mine = cost[costIndex(A, i)];
-        order[count[empty ? kEmptyClass : costClass(mine)][t]++] = i;
-        mine = empty ? 0u : 1u;
-    }
+    slots = lane < kCostClasses ? table[lane * kOrderWaves + wave] : 0u;
+    sweep(true);
 }
 
 // Batch form of getFinalColor (src/render.cpp:16-66): lane = caller-supplied ray.
@@ -1314,6 +1344,7 @@ struct DeviceCtx {
     // per-tile cost of the previous frame and the visiting order derived from it;
     // valid for the frame shape / partition recorded here
     uint32_t *blockCost = nullptr, *blockOrder = nullptr; // device: kMaxOrderedBlocks words each
+    uint8_t* blockClass = nullptr;                         // device: kMaxOrderedBlocks bytes
     uint32_t* queueBounds = nullptr;                      // device: the work queue's plan, written by orderBlocksKernel
     int costW = -1, costH = -1, costTile = -1, costRank = -1, costWorld = -1, costDriver = -1;
 };
@@ -1827,8 +1858,9 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
             c->costW = A.W, c->costH = A.H, c->costTile = g.ts, c->costRank = g.rank, c->costWorld = g.world, c->costDriver = driver;
         } else {
             auto envClass = [](const char* name, uint32_t fallback) { const char* e = getenv(name); return e ? uint32_t(atoi(e)) : fallback; };
-            hipLaunchKernelGGL(orderBlocksKernel, dim3(1), dim3(kOrderThreads), 0, c->stream, A, c->blockOrder, c->queueBounds, uint32_t(c->numCUs) * 16u,
-                envClass("RTX_SINGLE_CLASS", kLastSingleClass), envClass("RTX_HEAVY_CLASS", kLastHeavyClass));
+            hipLaunchKernelGGL(classifyBlocksKernel, dim3((A.blocksMine + 255u) / 256u), dim3(256), 0, c->stream, A, c->blockClass);
+            hipLaunchKernelGGL(orderBlocksKernel, dim3(1), dim3(kOrderThreads), 0, c->stream, c->blockClass, A.blocksMine, A.unitsPerBlockLog2, c->blockOrder, c->queueBounds,
+                uint32_t(c->numCUs) * 16u, envClass("RTX_SINGLE_CLASS", kLastSingleClass), envClass("RTX_HEAVY_CLASS", kLastHeavyClass));
             A.blockOrder = c->blockOrder;
             A.costFloor = kCostFloorTicks;
             A.work.plan = c->queueBounds;
@@ -1956,6 +1988,7 @@ int rtx_init(int device)
         HIP_TRY(hipMalloc((void**)&c->jump, kJumpCap * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->blockCost, (kMaxOrderedBlocks + 64) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->blockOrder, kMaxOrderedBlocks * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->blockClass, kMaxOrderedBlocks + 4));
         HIP_TRY(hipMalloc((void**)&c->queueBounds, 256));
         c->device = device;
     }
