@@ -1151,12 +1151,14 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
 // region 0 = the blocks up to class kLastSingleClass, one unit per claim; region 1 =
 // up to kLastHeavyClass, one to three units per claim depending on how many units
 // each wave will get; region 2 = the rest of the blocks that can see the scene, four.
-// Two kernels: classifyBlocksKernel (one thread per block) finds each block's class
-// and resets its cost for the new measurement: 1 (cheap until a unit reports
-// otherwise) for a block that can see the scene, 0 (never measured) for the others;
-// orderBlocksKernel (one workgroup) is a stable counting sort on the classes, each
-// wave owning a run of consecutive blocks.
-constexpr int kMaxOrderedBlocks = 1 << 20, kOrderThreads = 1024, kOrderWaves = kOrderThreads / 64, kCostClasses = 32;
+// A stable counting sort on the classes in three small kernels, one wave per 64
+// consecutive blocks (a "step"): classifyBlocksKernel finds each block's class, counts
+// the classes of its step into table[class][step] and resets the block's cost for the
+// new measurement: 1 (cheap until a unit reports otherwise) for a block that can see
+// the scene, 0 (never measured) for the others; scanBlocksKernel (one workgroup) turns
+// the table into places, class after class, and writes the plan; placeBlocksKernel
+// writes the order.
+constexpr int kMaxOrderedBlocks = 1 << 20, kScanThreads = 1024, kCostClasses = 32;
 // costs are in ticks of the 100 MHz wall clock; class 15 starts at 232 us, class 23 at 14.5 us
 constexpr uint32_t kLastSingleClass = 15, kLastHeavyClass = 23, kEmptyClass = kCostClasses - 1;
 constexpr uint32_t kCostFloorTicks = 256; // 2.5 us: well inside the cheapest classes
@@ -1170,85 +1172,96 @@ RTX_DEV uint32_t costClass(uint32_t c) // 0 = most expensive ... 30 = cheapest
         return level >= 44 ? 0 : 44 - level; // 1 .. 26
     return level >= 16 ? 27 : level >= 14 ? 28 : level >= 10 ? 29 : 30;
 }
-__global__ void __launch_bounds__(256) classifyBlocksKernel(RenderArgs A, uint8_t* classes)
+// The classes among a wave's 64 blocks, one after another (neighbouring blocks share
+// few): visit(class, lanes that hold it) is called with wave-uniform arguments.
+template <typename F>
+RTX_DEV void forEachClass(uint32_t cls, bool valid, F visit)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= A.blocksMine)
-        return;
-    const bool empty = placeBlock(A, i).culled; // (A.blockOrder is NULL here: list order)
-    uint32_t& mine = A.blockCost[costIndex(A, i)];
-    classes[i] = uint8_t(empty ? kEmptyClass : costClass(mine));
-    mine = empty ? 0u : 1u;
-}
-__global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(const uint8_t* classes, uint32_t n, int unitsPerBlockLog2, uint32_t* order, uint32_t* plan, uint32_t nWaves, uint32_t lastSingleClass,
-                                                                    uint32_t lastHeavyClass)
-{
-    // table[c][w]: blocks of class c in wave w's run; after the scan, where they go
-    __shared__ uint32_t table[kCostClasses * kOrderWaves];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t per = ((n + kOrderWaves * 64u - 1u) / (kOrderWaves * 64u)) * 64u, lo = min(n, wave * per), hi = min(n, lo + per);
-    // One step takes 64 consecutive blocks, lane = block, and visits the classes among
-    // them one after another (neighbouring blocks share few).  `slots` holds one number
-    // per class in lanes 0..31: the count so far (first pass), the next place (second).
-    uint32_t slots = 0;
-    // (kAhead steps' classes are read together: the reads' latency is what a step costs)
-    constexpr uint32_t kAhead = 8;
-    auto sweep = [&](bool place) {
-        for (uint32_t group = lo; group < hi; group += 64u * kAhead) {
-            uint32_t ahead[kAhead];
-#pragma unroll
-            for (uint32_t j = 0; j < kAhead; j++) {
-                const uint32_t i = group + j * 64u + lane;
-                ahead[j] = i < hi ? classes[i] : 0xffu;
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < kAhead; j++) {
-                const uint32_t i = group + j * 64u + lane, cls = ahead[j];
-                uint64_t rest = __ballot(i < hi);
-                while (rest) {
-                    const uint32_t b = uint32_t(__builtin_amdgcn_readlane(int(cls), __builtin_ctzll(rest)));
-                    const uint64_t same = __ballot(cls == b);
-                    if (place && cls == b) {
-                        const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(same >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(same), 0u));
-                        order[uint32_t(__builtin_amdgcn_readlane(int(slots), int(b))) + before] = i;
-                    }
-                    slots += lane == b ? uint32_t(__popcll(same)) : 0u;
-                    rest &= ~same;
-                }
-            }
-        }
-    };
-    sweep(false);
-    if (lane < kCostClasses)
-        table[lane * kOrderWaves + wave] = slots;
-    __syncthreads();
-    // exclusive prefix sum over the table, class after class
-    const uint32_t e = threadIdx.x;
-    const bool entry = e < kCostClasses * kOrderWaves;
-    const uint32_t mine = entry ? table[e] : 0u;
-    for (uint32_t step = 1; step < kCostClasses * kOrderWaves; step <<= 1) {
-        const uint32_t add = (entry && e >= step) ? table[e - step] : 0u;
-        __syncthreads();
-        if (entry)
-            table[e] += add;
-        __syncthreads();
+    uint64_t rest = __ballot(valid);
+    while (rest) {
+        const uint32_t b = uint32_t(__builtin_amdgcn_readlane(int(cls), __builtin_ctzll(rest)));
+        const uint64_t same = __ballot(valid && cls == b);
+        visit(b, same);
+        rest &= ~same;
     }
-    const uint32_t before = entry ? table[e] - mine : 0u;
+}
+__global__ void __launch_bounds__(256) classifyBlocksKernel(RenderArgs A, uint8_t* classes, uint32_t* table, uint32_t nSteps, uint32_t* clear, uint32_t clearWords)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, step = i >> 6;
+    // (the frame's ticket counters and statistics are zeroed on the way)
+    for (uint32_t w = i; w < clearWords; w += gridDim.x * 256u)
+        clear[w] = 0;
+    const bool valid = i < A.blocksMine;
+    uint32_t cls = 0;
+    if (valid) {
+        const bool empty = placeBlock(A, i).culled; // (A.blockOrder is NULL here: list order)
+        uint32_t& mine = A.blockCost[costIndex(A, i)];
+        cls = empty ? kEmptyClass : costClass(mine);
+        classes[i] = uint8_t(cls);
+        mine = empty ? 0u : 1u;
+    }
+    uint32_t counts = 0; // lane c: blocks of class c in this step
+    forEachClass(cls, valid, [&](uint32_t b, uint64_t same) { counts += lane == b ? uint32_t(__popcll(same)) : 0u; });
+    if (lane < kCostClasses && step < nSteps)
+        table[lane * nSteps + step] = counts;
+}
+__global__ void __launch_bounds__(kScanThreads) scanBlocksKernel(uint32_t* table, uint32_t nSteps, int unitsPerBlockLog2, uint32_t* plan, uint32_t nWaves, uint32_t lastSingleClass, uint32_t lastHeavyClass)
+{
+    // Exclusive prefix sum over the table read as one array.  Each wave owns a run of
+    // whole 64-entry rows (lane = entry, so the accesses coalesce): it adds its run up,
+    // the waves' totals are exchanged, then it goes over the run again with a running
+    // sum along the lanes and a carry from row to row.
+    __shared__ uint32_t waveTotal[kScanThreads / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, total = kCostClasses * nSteps;
+    const uint32_t rows = (total + 63u) / 64u, rowsPerWave = (rows + kScanThreads / 64 - 1) / (kScanThreads / 64);
+    const uint32_t lo = min(total, wave * rowsPerWave * 64u), hi = min(total, lo + rowsPerWave * 64u);
+    auto alongLanes = [&](uint32_t v) { // inclusive running sum
+        for (uint32_t o = 1; o < 64u; o <<= 1) {
+            const uint32_t up = uint32_t(__shfl_up(int(v), o, 64));
+            v += lane >= o ? up : 0u;
+        }
+        return v;
+    };
+    uint32_t mine = 0;
+    for (uint32_t base = lo; base < hi; base += 64u)
+        mine += base + lane < hi ? table[base + lane] : 0u;
+    mine = alongLanes(mine);
+    if (lane == 63u)
+        waveTotal[wave] = mine;
     __syncthreads();
-    if (entry)
-        table[e] = before;
-    __syncthreads();
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < wave; w++)
+        carry += waveTotal[w];
+    for (uint32_t base = lo; base < hi; base += 64u) {
+        const uint32_t v = base + lane < hi ? table[base + lane] : 0u;
+        const uint32_t upTo = alongLanes(v);
+        if (base + lane < hi)
+            table[base + lane] = carry + upTo - v;
+        carry += uint32_t(__builtin_amdgcn_readlane(int(upTo), 63));
+    }
+    __syncthreads(); // (one workgroup: its global writes are visible to it after the barrier)
     if (threadIdx.x == 0) {
-        const uint32_t end0 = table[(lastSingleClass + 1) * kOrderWaves] << unitsPerBlockLog2, end1 = table[(lastHeavyClass + 1) * kOrderWaves] << unitsPerBlockLog2;
+        const uint32_t end0 = table[(lastSingleClass + 1) * nSteps] << unitsPerBlockLog2, end1 = table[(lastHeavyClass + 1) * nSteps] << unitsPerBlockLog2;
         plan[0] = end0;
         plan[1] = end1;
-        plan[2] = table[kEmptyClass * kOrderWaves] << unitsPerBlockLog2;
+        plan[2] = table[kEmptyClass * nSteps] << unitsPerBlockLog2;
         plan[3] = 1;
         plan[4] = min(3u, max(1u, (end1 - end0) / (nWaves * 32u)));
         plan[5] = 4;
     }
-    slots = lane < kCostClasses ? table[lane * kOrderWaves + wave] : 0u;
-    sweep(true);
+}
+__global__ void __launch_bounds__(256) placeBlocksKernel(const uint8_t* classes, uint32_t n, const uint32_t* table, uint32_t nSteps, uint32_t* order)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, step = i >> 6;
+    const bool valid = i < n;
+    const uint32_t cls = valid ? classes[i] : 0u;
+    const uint32_t places = (lane < kCostClasses && step < nSteps) ? table[lane * nSteps + step] : 0u; // lane c: where the step's class c goes
+    forEachClass(cls, valid, [&](uint32_t b, uint64_t same) {
+        if (valid && cls == b) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(same >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(same), 0u));
+            order[uint32_t(__builtin_amdgcn_readlane(int(places), int(b))) + before] = i;
+        }
+    });
 }
 
 // Batch form of getFinalColor (src/render.cpp:16-66): lane = caller-supplied ray.
@@ -1345,7 +1358,8 @@ struct DeviceCtx {
     // valid for the frame shape / partition recorded here
     uint32_t *blockCost = nullptr, *blockOrder = nullptr; // device: kMaxOrderedBlocks words each
     uint8_t* blockClass = nullptr;                         // device: kMaxOrderedBlocks bytes
-    uint32_t* queueBounds = nullptr;                      // device: the work queue's plan, written by orderBlocksKernel
+    uint32_t* classTable = nullptr;                        // device: kCostClasses x (kMaxOrderedBlocks / 64) words
+    uint32_t* queueBounds = nullptr;                      // device: the work queue's plan, written by scanBlocksKernel
     int costW = -1, costH = -1, costTile = -1, costRank = -1, costWorld = -1, costDriver = -1;
 };
 constexpr size_t kTicketBytes = size_t(kQueues) * kQueueStride * sizeof(uint32_t), kStatBytes = size_t(kStatSlots) * kStatStride * sizeof(unsigned long long);
@@ -1557,8 +1571,7 @@ int traceImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* d
     A.work.nUnits = uint32_t((n + 63) / 64);
     A.work = makeQueue(c, A.work.nUnits);
     A.stats = c->stats;
-    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes, c->stream));
-    HIP_TRY(hipMemsetAsync(c->stats, 0, kStatBytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
         const bool count = wantCounters();
@@ -1837,9 +1850,6 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
             c->jumpW = A.W, c->jumpH = A.H, c->jumpS = A.samples, c->jumpD = d;
         }
     }
-    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes, c->stream));
-    HIP_TRY(hipMemsetAsync(c->stats, 0, kStatBytes, c->stream));
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
     // Longest blocks first: some units (grazing shadow rays, silhouettes) run fifty times
     // the average, and a frame is not done before the last of them, so the 8x8 blocks
     // are started in the order of the longest unit each held on the previous frame of
@@ -1847,26 +1857,33 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // device, on the stream, with no host round trip.  The image does not depend on it.
     A.blockOrder = nullptr;
     A.blockCost = nullptr;
+    bool ordered = false;
     A.blocksMine = uint32_t(g.tilesMine) * A.blocksPerTile;
     A.costStride = (A.blocksMine + 63u) / 64u;
     A.costFloor = 0;
     if (A.unitsPerBlockLog2 >= 0 && A.blocksMine > 1 && A.blocksMine <= uint32_t(kMaxOrderedBlocks) && !getenv("RTX_NO_TILE_ORDER")) {
         A.blockCost = c->blockCost;
-        if (c->costW != A.W || c->costH != A.H || c->costTile != g.ts || c->costRank != g.rank || c->costWorld != g.world || c->costDriver != driver) {
+        ordered = !(c->costW != A.W || c->costH != A.H || c->costTile != g.ts || c->costRank != g.rank || c->costWorld != g.world || c->costDriver != driver);
+        if (!ordered) {
             // nothing measured yet for frames of this shape: this one runs in list order
             HIP_TRY(hipMemsetAsync(c->blockCost, 0, size_t(A.costStride) * 64 * sizeof(uint32_t), c->stream));
             c->costW = A.W, c->costH = A.H, c->costTile = g.ts, c->costRank = g.rank, c->costWorld = g.world, c->costDriver = driver;
         } else {
             auto envClass = [](const char* name, uint32_t fallback) { const char* e = getenv(name); return e ? uint32_t(atoi(e)) : fallback; };
-            hipLaunchKernelGGL(classifyBlocksKernel, dim3((A.blocksMine + 255u) / 256u), dim3(256), 0, c->stream, A, c->blockClass);
-            hipLaunchKernelGGL(orderBlocksKernel, dim3(1), dim3(kOrderThreads), 0, c->stream, c->blockClass, A.blocksMine, A.unitsPerBlockLog2, c->blockOrder, c->queueBounds,
-                uint32_t(c->numCUs) * 16u, envClass("RTX_SINGLE_CLASS", kLastSingleClass), envClass("RTX_HEAVY_CLASS", kLastHeavyClass));
+            const uint32_t nSteps = (A.blocksMine + 63u) / 64u, groups = (A.blocksMine + 255u) / 256u;
+            hipLaunchKernelGGL(classifyBlocksKernel, dim3(groups), dim3(256), 0, c->stream, A, c->blockClass, c->classTable, nSteps, c->tickets, uint32_t((kTicketBytes + kStatBytes) / sizeof(uint32_t)));
+            hipLaunchKernelGGL(scanBlocksKernel, dim3(1), dim3(kScanThreads), 0, c->stream, c->classTable, nSteps, A.unitsPerBlockLog2, c->queueBounds, uint32_t(c->numCUs) * 16u,
+                envClass("RTX_SINGLE_CLASS", kLastSingleClass), envClass("RTX_HEAVY_CLASS", kLastHeavyClass));
+            hipLaunchKernelGGL(placeBlocksKernel, dim3(groups), dim3(256), 0, c->stream, c->blockClass, A.blocksMine, c->classTable, nSteps, c->blockOrder);
             A.blockOrder = c->blockOrder;
             A.costFloor = kCostFloorTicks;
             A.work.plan = c->queueBounds;
             A.work.nChunks = A.work.nUnits; // (for the grid size: at most)
         }
     }
+    if (!ordered)
+        HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
+    HIP_TRY(hipEventRecord(c->ev0, c->stream)); // kernel_ms is the render kernel's time
     if (A.work.nUnits) {
         const bool count = wantCounters();
         switch (stack) {
@@ -1937,8 +1954,7 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
     S.rays = dRays;
     S.out = dOut;
     S.n = n;
-    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes, c->stream));
-    HIP_TRY(hipMemsetAsync(c->stats, 0, kStatBytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
         const bool count = wantCounters();
@@ -1983,12 +1999,13 @@ int rtx_init(int device)
         c->stream = c->ownStream;
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev1));
-        HIP_TRY(hipMalloc((void**)&c->tickets, kTicketBytes));
-        HIP_TRY(hipMalloc((void**)&c->stats, kStatBytes));
+        HIP_TRY(hipMalloc((void**)&c->tickets, kTicketBytes + kStatBytes)); // one allocation: cleared together
+        c->stats = reinterpret_cast<unsigned long long*>(c->tickets + kTicketBytes / sizeof(uint32_t));
         HIP_TRY(hipMalloc((void**)&c->jump, kJumpCap * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->blockCost, (kMaxOrderedBlocks + 64) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->blockOrder, kMaxOrderedBlocks * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->blockClass, kMaxOrderedBlocks + 4));
+        HIP_TRY(hipMalloc((void**)&c->classTable, size_t(kCostClasses) * (kMaxOrderedBlocks / 64) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->queueBounds, 256));
         c->device = device;
     }
