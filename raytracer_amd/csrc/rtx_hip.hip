@@ -1861,7 +1861,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.blocksMine = uint32_t(g.tilesMine) * A.blocksPerTile;
     A.costStride = (A.blocksMine + 63u) / 64u;
     A.costFloor = 0;
-    if (A.unitsPerBlockLog2 >= 0 && A.blocksMine > 1 && A.blocksMine <= uint32_t(kMaxOrderedBlocks) && !getenv("RTX_NO_TILE_ORDER")) {
+    if (A.unitsPerBlockLog2 >= 0 && A.blocksMine > 1 && A.blocksMine <= uint32_t(kMaxOrderedBlocks) && !getenv("RTX_NO_BLOCK_ORDER")) {
         A.blockCost = c->blockCost;
         ordered = !(c->costW != A.W || c->costH != A.H || c->costTile != g.ts || c->costRank != g.rank || c->costWorld != g.world || c->costDriver != driver);
         if (!ordered) {
