@@ -318,6 +318,10 @@ struct LaneStack {
 
 struct TraceCounters {
     uint32_t boxTests, triTests;
+#ifdef RTX_PROBE
+    uint32_t outer = 0, inner = 0; // this lane's trips through the traversal loop and the leaf loop
+    uint32_t waveOuter = 0, waveInner = 0; // trips in which this lane was the lowest active one: summed over the wave, the wave's trips
+#endif
 };
 
 // Closest hit of one ray (BoundingVolumeHierarchy::intersect,
@@ -359,11 +363,20 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
     int sp = 0;
     int32_t cur = sc.rootRef;
     bool have = true;
+    // One record per trip whatever its kind: node and triangle records are both four
+    // float4, so every lane fetches its next record with the same four loads, the lanes
+    // at inner nodes then test their two boxes and the lanes inside leaves their one
+    // triangle.  No lane waits for the longest leaf among the wave's lanes.
     while (have) {
-        if (cur >= 0) {
-            // node record: X = (lo0.x, lo1.x, hi0.x, hi1.x), Y, Z likewise, W = (ref0, ref1, -, -)
-            const float4* np = sc.nodes + size_t(cur) * 4;
-            const float4 X = np[0], Y = np[1], Z = np[2], W = np[3];
+#ifdef RTX_PROBE
+        tc.outer++;
+        tc.waveOuter += uint32_t(__builtin_ctzll(__ballot(1))) == (threadIdx.x & 63u);
+#endif
+        const bool isNode = cur >= 0;
+        const float4* p = isNode ? sc.nodes + size_t(cur) * 4 : sc.tris + size_t(~cur) * 4;
+        const float4 X = p[0], Y = p[1], Z = p[2], W = p[3];
+        bool popNext = true;
+        if (isNode) {
             float k0, k1;
             if (COUNT)
                 tc.boxTests += 2;
@@ -379,41 +392,39 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
                 const bool firstIs1 = k1 < k0;
                 st.push(sp++, firstIs1 ? r0 : r1, firstIs1 ? k0 : k1);
                 cur = firstIs1 ? r1 : r0;
-                continue;
-            } else if (h0) {
-                cur = r0;
-                continue;
-            } else if (h1) {
-                cur = r1;
-                continue;
+                popNext = false;
+            } else if (h0 || h1) {
+                cur = h0 ? r0 : r1;
+                popNext = false;
             }
         } else {
-            int k = ~cur;
-            for (;;) {
-                const float4* p = sc.tris + size_t(k) * 4;
-                const float4 X = p[0], Y = p[1], Z = p[2], W = p[3];
-                if (COUNT)
-                    tc.triTests++;
-                float th;
-                if (triangleTestPacked(X, Y, Z, W.x, o, d, t, th)) {
-                    t = th;
-                    bestK = k;
-                }
-                if (__float_as_int(W.w) & RTX_TRI_LAST_IN_LEAF)
-                    break;
-                k++;
+            if (COUNT)
+                tc.triTests++;
+#ifdef RTX_PROBE
+            tc.inner++;
+            tc.waveInner += uint32_t(__builtin_ctzll(__ballot(1))) == (threadIdx.x & 63u);
+#endif
+            float th;
+            if (triangleTestPacked(X, Y, Z, W.x, o, d, t, th)) {
+                t = th;
+                bestK = ~cur;
+                if (EARLY && t < tStop)
+                    return;
             }
-            if (EARLY && t < tStop)
-                return;
+            if (!(__float_as_int(W.w) & RTX_TRI_LAST_IN_LEAF)) {
+                cur--;
+                popNext = false;
+            }
         }
-        // pop the next node that is still worth visiting
-        have = false;
-        while (sp > 0) {
-            float key;
-            st.pop(--sp, cur, key);
-            if (!(t < key)) {
-                have = true;
-                break;
+        if (popNext) {
+            have = false;
+            while (sp > 0) {
+                float key;
+                st.pop(--sp, cur, key);
+                if (!(t < key)) {
+                    have = true;
+                    break;
+                }
             }
         }
     }

@@ -53,6 +53,12 @@ struct LaneCounters {
     RTX_DEV void countShaded(bool lane) { shaded += __popcll(__ballot(lane)); }
 };
 
+#ifdef RTX_PROBE
+// diagnostic build: per unit of the last frame (ticks, longest lane's loop trips, longest lane's leaf trips, sum of the lanes' loop trips)
+constexpr uint32_t kProbeUnits = 1u << 20;
+__device__ uint4 g_probe[kProbeUnits];
+#endif
+
 RTX_DEV uint64_t waveSum(uint32_t v)
 {
     uint64_t s = v;
@@ -116,10 +122,12 @@ struct WorkQueue {
     uint32_t* tickets;
     uint32_t nUnits, chunk, nChunks;
     const uint32_t* plan; // device, NULL: one region of `chunk` units per claim
+    uint32_t aheadFrom;   // first region whose chunks are claimed ahead (0: all of them)
 };
 struct WorkCursor {
     uint32_t queue;  // wave-uniform: the counter this wave draws from
     uint32_t ticket; // lane 0: result of the claim in flight
+    bool claimed;    // wave-uniform: a claim is in flight
     // wave-uniform: where the regions end, in units and in chunks (cumulative), and their chunk sizes
     uint32_t endUnit[kRegions], endChunk[kRegions], chunk[kRegions];
 };
@@ -129,6 +137,7 @@ RTX_DEV void claimTicket(const WorkQueue& q, WorkCursor& w)
     if ((threadIdx.x & 63) == 0)
         k = atomicAdd(q.tickets + w.queue * kQueueStride, 1u);
     w.ticket = k;
+    w.claimed = true;
 }
 RTX_DEV void openCursor(const WorkQueue& q, WorkCursor& w)
 {
@@ -152,11 +161,17 @@ RTX_DEV void openCursor(const WorkQueue& q, WorkCursor& w)
 RTX_DEV bool nextChunk(const WorkQueue& q, WorkCursor& w, uint32_t& first, uint32_t& last)
 {
     for (;;) {
+        if (!w.claimed)
+            claimTicket(q, w);
         const uint32_t k = __builtin_amdgcn_readfirstlane(w.ticket);
+        w.claimed = false;
         const uint64_t id = uint64_t(k) * kQueues + w.queue;
         if (id < w.endChunk[kRegions - 1]) {
-            claimTicket(q, w);
             const uint32_t c = uint32_t(id);
+            // claim the next chunk now, so that the atomic's round trip hides behind this
+            // chunk's work (see makeQueue for when the longest blocks are left out)
+            if (!q.plan || q.aheadFrom == 0 || c >= w.endChunk[q.aheadFrom - 1])
+                claimTicket(q, w);
             if (c < w.endChunk[0]) {
                 first = c * w.chunk[0];
                 last = min(first + w.chunk[0], w.endUnit[0]);
@@ -1004,6 +1019,10 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
             continue;
         }
         const uint64_t unitBegan = place.costSlot >= 0 ? wall_clock64() : 0;
+#ifdef RTX_PROBE
+        const uint64_t probeBegan = wall_clock64();
+        const uint32_t probeOuter = lc.tc.outer, probeInner = lc.tc.inner, probeWaveOuter = lc.tc.waveOuter, probeWaveInner = lc.tc.waveInner;
+#endif
         const uint32_t storeIndex = place.ok ? place.outIndex : 0xffffffffu; // where this lane's pixel goes in the output; ~0: nowhere
         V3 carry = mk(0, 0, 0); // sum of the rounds so far (a pixel with more than 64 samples owns the wave)
         for (int round = 0; round < A.rounds; round++) {
@@ -1127,6 +1146,19 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                 dst[2] = px.z;
             }
         }
+#ifdef RTX_PROBE
+        {
+            uint32_t mo = lc.tc.outer - probeOuter, mi = lc.tc.inner - probeInner;
+            const uint32_t so = uint32_t(waveSum(mo));
+            const uint32_t wo = uint32_t(waveSum(lc.tc.waveOuter - probeWaveOuter)), wi = uint32_t(waveSum(lc.tc.waveInner - probeWaveInner));
+            for (int off = 32; off > 0; off >>= 1) {
+                mo = max(mo, uint32_t(__shfl_xor(int(mo), off, 64)));
+                mi = max(mi, uint32_t(__shfl_xor(int(mi), off, 64)));
+            }
+            if (lane == 0 && unit < kProbeUnits)
+                g_probe[unit] = make_uint4(uint32_t(wall_clock64() - probeBegan), mo | (mi << 16), wo | (wi << 16), uint32_t(probeBegan));
+        }
+#endif
         // the longest unit of each block decides how early the block starts next frame
         if (place.costSlot >= 0)
             costTicks = max(costTicks, uint32_t(min(wall_clock64() - unitBegan, uint64_t(0xfffffffeu))));
@@ -1452,6 +1484,14 @@ WorkQueue makeQueue(const DeviceCtx* c, uint32_t nUnits)
         q.chunk = uint32_t(std::max(1, atoi(e)));
     q.nChunks = uint32_t((uint64_t(nUnits) + q.chunk - 1) / q.chunk);
     q.plan = nullptr;
+    // A frame spread thinly over the chip (one rank's share of it: a handful of chunks
+    // per wave) ends on its longest units, and a wave that holds its next chunk while
+    // it works through one of them keeps that chunk from the waves that have fallen
+    // idle; there the chunks of the longest blocks are claimed when needed.  A frame
+    // that keeps every wave busy for long is better off with every claim made ahead.
+    q.aheadFrom = nUnits < waves * 24u ? 1 : 0;
+    if (const char* e = getenv("RTX_CLAIM_AHEAD_FROM")) // diagnostic
+        q.aheadFrom = uint32_t(std::min(kRegions - 1, std::max(0, atoi(e))));
     return q;
 }
 
@@ -2381,6 +2421,16 @@ int rtx_set_stream(void* hipStream)
     g_ctx->stream = hipStream ? static_cast<hipStream_t>(hipStream) : g_ctx->ownStream;
     return RTX_OK;
 }
+
+#ifdef RTX_PROBE
+int rtx_debug_probe(void* out, size_t nUnits)
+{
+    if (nUnits > kProbeUnits)
+        return RTX_ERR_LIMIT;
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), nUnits * sizeof(uint4)) == hipSuccess ? RTX_OK : RTX_ERR_DEVICE;
+}
+#endif
 
 int rtx_synchronize(void)
 {

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""What one rank of an N-rank frame costs, measured on ONE GPU: for N in 1,2,4,8 and
+every rank r < N, the device time per frame of rtx_render_tiles_device (tile t ->
+rank t % N), the host time to enqueue it, and the time of rtx_detile_device on
+rank 0.  The gather between them needs N GPUs and is not measured here.
+
+    python tools/scale_probe.py [--steps 20]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--worlds", default="1,2,4,8")
+    args = ap.parse_args()
+    import torch
+    from raytracer_amd import abi, engine
+    from raytracer_amd.scene import dragon_scene, make_camera, make_params
+
+    hip = engine.hip_lib()
+    W, H = 1920, 1080
+    f = abi.features(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
+    gpu = engine.GpuEngine(dragon_scene(), f)
+    cam = engine.device_camera(make_camera(), W, H)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert hip.rtx_set_stream(C.c_void_p(stream.cuda_stream)) == 0
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    for world in [int(w) for w in args.worlds.split(",")]:
+        worst = 0.0
+        for rank in range(world):
+            rp = make_params(W, H, driver=abi.DRIVER_MRAYS, samples=16, tile_size=args.tile, tile_rank=rank, tile_world=world)
+            per = hip.rtx_tiles_per_rank(C.byref(rp))
+            tiles = torch.zeros((per, args.tile, args.tile, 3), dtype=torch.float32, device=dev)
+
+            def step():
+                rc = hip.rtx_render_tiles_device(gpu.device_scene(), C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(tiles.data_ptr()), None)
+                assert rc == 0, hip.rtx_last_error()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            for _ in range(args.steps):
+                step()
+            e1.record(stream)
+            host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            dev_ms = e0.elapsed_time(e1) / args.steps
+            worst = max(worst, dev_ms)
+            print(f"world {world} rank {rank}: device {dev_ms*1e3:7.1f} us/frame, host enqueue {host/args.steps*1e6:6.1f} us/frame", flush=True)
+        rp = make_params(W, H, driver=abi.DRIVER_MRAYS, samples=16, tile_size=args.tile, tile_rank=0, tile_world=world)
+        per = hip.rtx_tiles_per_rank(C.byref(rp))
+        allt = torch.zeros((world, per, args.tile, args.tile, 3), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            hip.rtx_detile_device(C.c_void_p(allt.data_ptr()), C.byref(rp), C.c_void_p(frame.data_ptr()))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            hip.rtx_detile_device(C.c_void_p(allt.data_ptr()), C.byref(rp), C.c_void_p(frame.data_ptr()))
+        e1.record(stream)
+        torch.cuda.synchronize()
+        det = e0.elapsed_time(e1) / args.steps
+        print(f"world {world}: slowest rank {worst*1e3:.1f} us, detile {det*1e3:.1f} us  -> ideal {1371.0/world:.1f} us", flush=True)
+    gpu.close()
+
+
+if __name__ == "__main__":
+    main()
