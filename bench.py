@@ -10,7 +10,9 @@ A step is one frame.  The scene, its BVH and the framebuffer live in HBM before
 the timed region starts; nothing crosses PCIe inside it.  With N > 1 the frame
 is cut into interleaved 32x32 tiles (tile t -> rank t % N), every rank renders
 its tiles and the framebuffer is assembled on rank 0 by one RCCL gather per
-frame; total work is fixed, so scaling is "strong".
+frame; total work is fixed, so scaling is "strong".  Frames are double-buffered:
+the gather of frame i runs on the collective's stream while frame i + 1 is
+rendered, and every frame is assembled on rank 0 inside the timed region.
 
 data/dragon.obj is not part of the reference checkout, so the geometry is the
 seeded stand-in of raytracer_amd.scene.dragon_standin (81 920 triangles, unit
@@ -93,12 +95,13 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-GPU render of it")
+    ap.add_argument("--force-pipeline", action="store_true", help="rehearsal: run the N > 1 code path (tiles, gather, assembly) in a one-rank group")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from raytracer_amd import abi, engine
-    from raytracer_amd.distributed import gather_tiles
+    from raytracer_amd.distributed import FramePipeline
     from raytracer_amd.scene import SceneData, dragon_scene, make_camera, make_params
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,11 +117,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    grouped = world > 1 or args.force_pipeline
+    if grouped:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     hip = engine.hip_lib()
     scene = SceneData.load(args.obj_npz) if args.obj_npz else dragon_scene()
@@ -140,24 +147,26 @@ def main():
 
     pixels = args.width * args.height
     frame = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
-    if world > 1:
-        per = hip.rtx_tiles_per_rank(C.byref(rp))
-        tiles = torch.zeros((per, args.tile, args.tile, 3), dtype=torch.float32, device=dev)
-        gathered = torch.zeros((world,) + tuple(tiles.shape), dtype=torch.float32, device=dev) if rank == 0 else None
-
-    def step(stats=None):
-        sp = C.byref(stats) if stats is not None else None
-        if world == 1:
-            rc = hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(frame.data_ptr()), sp)
-        else:
-            rc = hip.rtx_render_tiles_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(tiles.data_ptr()), sp)
-            if args.backend != "nccl":
-                torch.cuda.current_stream().synchronize()   # host-staged rehearsal path
-            gather_tiles(tiles, dst=0, out=gathered)
-            if rank == 0 and rc == 0:
-                rc = hip.rtx_detile_device(C.c_void_p(gathered.data_ptr()), C.byref(rp), C.c_void_p(frame.data_ptr()))
+    def check(rc):
         if rc != 0:
             raise RuntimeError(hip.rtx_last_error().decode())
+
+    pipe = None
+    if grouped:
+        per = hip.rtx_tiles_per_rank(C.byref(rp))
+        pipe = FramePipeline(
+            lambda: torch.zeros((per, args.tile, args.tile, 3), dtype=torch.float32, device=dev),
+            lambda tiles: check(hip.rtx_render_tiles_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(tiles.data_ptr()), None)),
+            lambda stack: check(hip.rtx_detile_device(C.c_void_p(stack.data_ptr()), C.byref(rp), C.c_void_p(frame.data_ptr()))))
+
+    def step(stats=None):
+        if pipe is not None:
+            if stats is not None:   # the counted frame: this rank's tiles alone, waited for
+                check(hip.rtx_render_tiles_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(pipe.tiles[0].data_ptr()), C.byref(stats)))
+            else:
+                pipe.submit()
+        else:
+            check(hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(frame.data_ptr()), C.byref(stats) if stats is not None else None))
 
     # one counted frame: rays per frame (deterministic) and this rank's kernel time
     st = abi.Stats()
@@ -165,6 +174,8 @@ def main():
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.drain()
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the small reductions live
     counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce, st.shaded_hits], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -180,6 +191,8 @@ def main():
     ev0.record(stream)
     for _ in range(args.steps):
         step()
+    if pipe is not None:
+        pipe.drain()          # the last frame's gather and assembly belong to the timed region
     ev1.record(stream)
     if world > 1:
         dist.barrier()
@@ -191,7 +204,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax[0])
 
-    if rank == 0 and args.check and world > 1:
+    if rank == 0 and args.check and grouped:
         ref = torch.zeros_like(frame)
         one = make_params(args.width, args.height, driver=abi.DRIVER_MRAYS, samples=args.spp, tile_size=args.tile)
         rc = hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(one), C.c_void_p(ref.data_ptr()), None)
@@ -209,10 +222,10 @@ def main():
                                    f"{args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light, sweep-split BVH "
                                    f"({gpu.levels()} levels, {gpu.leaves()} leaves)",
                        "rays_per_frame": int(rays_frame), "primary": int(counts[0]), "shadow": int(counts[1]),
-                       "partition": "whole frame" if world == 1 else f"interleaved {args.tile}x{args.tile} tiles + RCCL gather to rank 0",
+                       "partition": "whole frame" if not grouped else f"interleaved {args.tile}x{args.tile} tiles + RCCL gather to rank 0",
                        "bvh_build_upload_s": round(t_build, 3)},
         }
-        if world == 1:
+        if not grouped:
             cb, n_aabb, n_tri = (None, None, None)
             if not args.no_cpu_baseline:
                 cb, n_aabb, n_tri = cpu_baseline(scene, features, cam_in, args)
@@ -233,7 +246,7 @@ def main():
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     gpu.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -72,3 +72,60 @@ def gather_tiles(local_tiles, dst=0, out=None):
         return buf
     dist.gather(staged, None, dst=dst)
     return None
+
+
+class FramePipeline:
+    """Double-buffered frame assembly: the gather of frame i runs on the
+    collective's own stream while frame i + 1 is being rendered, and frame i is
+    scattered into the Screen-layout image once frame i + 1 has been queued.
+
+        pipe = FramePipeline(make_buffer, render, assemble)
+        for _ in range(n): pipe.submit()
+        pipe.drain()
+
+    `make_buffer()` returns a fresh compact tile tensor; `render(tiles)` queues
+    this rank's tiles of the next frame into it; `assemble(stack)` (called on dst
+    only) scatters the gathered rank-major stack.  Every frame submitted is
+    gathered and assembled, in order; drain() finishes the last one.  With a
+    backend that cannot take the tensors as they are (gloo and GPU tensors) the
+    frames are gathered one after the other through gather_tiles."""
+
+    def __init__(self, make_buffer, render, assemble, dst=0):
+        import torch
+        import torch.distributed as dist
+        self.render, self.assemble, self.dst = render, assemble, dst
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.tiles = [make_buffer(), make_buffer()]
+        t = self.tiles[0]
+        self.overlapped = not (t.is_cuda and dist.get_backend() == "gloo")
+        self.stacks = [torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if self.rank == dst else None for _ in range(2)]
+        self.pending = None   # (work, buffer index) of the gather in flight
+        self.frames = 0
+
+    def _finish(self):
+        if self.pending is None:
+            return
+        work, k = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()       # a device-side wait under the nccl backend: the host does not block
+        if self.rank == self.dst:
+            self.assemble(self.stacks[k])
+
+    def submit(self):
+        import torch.distributed as dist
+        k = self.frames & 1
+        self.frames += 1
+        self.render(self.tiles[k])
+        if not self.overlapped:
+            gather_tiles(self.tiles[k], dst=self.dst, out=self.stacks[k])
+            self.pending = (None, k)
+            self._finish()
+            return
+        outs = list(self.stacks[k].unbind(0)) if self.rank == self.dst else None
+        work = dist.gather(self.tiles[k], outs, dst=self.dst, async_op=True)
+        self._finish()        # the frame before this one: its gather has had this frame's render to hide behind
+        self.pending = (work, k)
+
+    def drain(self):
+        self._finish()

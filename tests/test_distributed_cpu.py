@@ -37,6 +37,45 @@ def _worker(rank, world, port, width, height, tile, out_path):
     dist.destroy_process_group()
 
 
+def _pipeline_worker(rank, world, port, width, height, tile, out_path):
+    """Five different frames through the double-buffered pipeline: every one must
+    come out assembled, in order, although each gather overlaps the next render."""
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.distributed import FramePipeline
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(11)
+    frames = [rng.random((height, width, 3)).astype(np.float32) for _ in range(5)]
+    per = tiles_per_rank(width, height, tile, world)
+    state = {"next": 0}
+    rebuilt = []
+
+    def render(tiles):
+        tiles.copy_(torch.from_numpy(extract_tiles(frames[state["next"]], tile, rank, world)))
+        state["next"] += 1
+
+    pipe = FramePipeline(lambda: torch.zeros((per, tile, tile, 3), dtype=torch.float32), render,
+                         lambda stack: rebuilt.append(assemble_tiles(stack.numpy().copy(), width, height, tile, world)))
+    for _ in frames:
+        pipe.submit()
+    pipe.drain()
+    if rank == 0:
+        np.save(out_path, np.array([len(rebuilt) == len(frames)] + [np.array_equal(a, b) for a, b in zip(rebuilt, frames)]))
+    else:
+        assert not rebuilt
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_frame_pipeline_assembles_every_frame_in_order(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), 100, 70, 16, out), nprocs=2, join=True)
+    ok = np.load(out)
+    assert len(ok) == 6 and ok.all()
+
+
 @pytest.mark.parametrize("width,height,tile", [(100, 70, 16), (64, 64, 32), (33, 9, 8)])
 def test_two_rank_tile_gather_rebuilds_the_frame(tmp_path, width, height, tile):
     import torch.multiprocessing as mp
