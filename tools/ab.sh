@@ -1,15 +1,15 @@
 #!/bin/bash
-# A/B timing on the GPU box: every exp/*.so is a build of the HIP library; each is
-# put in place of raytracer_amd/librtx_hip.so (the box's copy of the tree is
-# scratch) and the workload probe is run on it.
-# Usage: tools/ab.sh "variation,variation" [reps]
+# A/B on the GPU box: each library named on the command line is put in place of
+# raytracer_amd/librtx_hip.so (the box's tree is scratch), then the per-rank scaling
+# probe and the workload probe are run on it.
+# Usage: tools/ab.sh "variation,variation" exp/a.so exp/b.so ...
 set -e
-only=${1:-headline,looking away,close-up d=1.2}
-reps=${2:-5}
+only=$1; shift
 cp raytracer_amd/librtx_hip.so /tmp/librtx_hip.orig.so
-for so in exp/*.so; do
+for so in "$@"; do
   echo "== $so"
   cp "$so" raytracer_amd/librtx_hip.so
-  timeout -k 10 120 python -u tools/perf_probe.py --only "$only" --reps "$reps" 2>&1 | grep -v amdgpu.ids
+  timeout -k 10 100 python -u tools/scale_probe.py --worlds 1,4,8 --steps 30 2>&1 | grep "^world [0-9]:"
+  timeout -k 10 150 python -u tools/perf_probe.py --only "$only" --reps 5 2>&1 | grep -v amdgpu.ids
 done
 cp /tmp/librtx_hip.orig.so raytracer_amd/librtx_hip.so
