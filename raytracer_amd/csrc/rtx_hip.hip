@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -251,6 +252,7 @@ struct FastDiv {
 };
 RTX_DEV uint32_t fastDiv(uint32_t n, FastDiv d) { return d.mul ? (__umulhi(n, d.mul) >> d.shift) : n; }
 
+constexpr int kMaxCutBoxes = 64;
 struct RenderArgs {
     DScene sc;
     rtx_features f;
@@ -282,6 +284,12 @@ struct RenderArgs {
     // scene's bounds from this camera: a block entirely outside is black without a
     // single ray being made (cullOn; see cullRectangle on the host side).
     int32_t cullOn, cullX0, cullX1, cullY0, cullY1;
+    // The same statement one step finer: the boxes of a shallow cut through the tree
+    // (every triangle lies in one of them), each projected like the root box.  A block
+    // outside all of these rectangles cannot see the scene either.  Used when the blocks
+    // are classified for the frame's order; 0 rectangles: the root rectangle alone counts.
+    int32_t nCutRects;
+    int32_t cutRects[kMaxCutBoxes][4]; // x0, x1, y0, y1 (y bottom-up), inclusive
     // 8x8 blocks are visited in the order blockOrder gives (position in the unit
     // sequence -> index into this rank's blocks, tile after tile), longest-running
     // first as measured on the previous frame; blockCost collects this frame's
@@ -1226,7 +1234,15 @@ __global__ void __launch_bounds__(256) classifyBlocksKernel(RenderArgs A, uint8_
     const bool valid = i < A.blocksMine;
     uint32_t cls = 0;
     if (valid) {
-        const bool empty = placeBlock(A, i).culled; // (A.blockOrder is NULL here: list order)
+        const BlockPlace b = placeBlock(A, i); // (A.blockOrder is NULL here: list order)
+        bool empty = b.culled;
+        if (!empty && A.nCutRects > 0) {
+            const int bx0 = int(b.x0), yHigh = A.H - 1 - int(b.y0), yLow = yHigh - 7;
+            bool seen = false;
+            for (int r = 0; r < A.nCutRects && !seen; r++)
+                seen = !(bx0 + 7 < A.cutRects[r][0] || bx0 > A.cutRects[r][1] || yHigh < A.cutRects[r][2] || yLow > A.cutRects[r][3]);
+            empty = !seen;
+        }
         uint32_t& mine = A.blockCost[costIndex(A, i)];
         cls = empty ? kEmptyClass : costClass(mine);
         classes[i] = uint8_t(cls);
@@ -1425,6 +1441,9 @@ struct rtx_scene {
     int numLevels = 0;
     bool hasEnv = false;
     bool hasAreaLight = false; // a segment or parallelogram light
+    // boxes of a shallow cut through the tree (at most kMaxCutBoxes; every triangle lies
+    // in one of them), for the per-frame visibility rectangles
+    std::vector<std::array<float, 6>> cutBoxes;
 };
 
 namespace {
@@ -1690,13 +1709,8 @@ FastDiv makeFastDiv(uint32_t d)
 // far beyond what rounding in the reference's slab test could bridge, so it misses
 // the root box there too and the pixel is black.  Returns false when no such
 // statement can be made (camera inside the bounds).
-bool cullRectangle(const rtx_scene* scene, const rtx_camera* cam, int W, int H, int32_t& x0, int32_t& x1, int32_t& y0, int32_t& y1)
+bool cullRectangle(const float* boxLo, const float* boxHi, const rtx_camera* cam, int W, int H, int32_t& x0, int32_t& x1, int32_t& y0, int32_t& y1)
 {
-    if (scene->d.rootRef == kEmptyRoot) { // nothing to hit at all
-        x0 = y0 = 1;
-        x1 = y1 = 0;
-        return true;
-    }
     // world -> camera space: the conjugate of the camera's rotation applied to p - position
     const double qw = cam->quat[0], qx = -cam->quat[1], qy = -cam->quat[2], qz = -cam->quat[3];
     auto toCamera = [&](const double p[3], double out[3]) {
@@ -1707,8 +1721,8 @@ bool cullRectangle(const rtx_scene* scene, const rtx_camera* cam, int W, int H, 
     };
     double centre[3], half[3], half2 = 0, extent = 0;
     for (int i = 0; i < 3; i++) {
-        centre[i] = 0.5 * (double(scene->d.rootLo[i]) + double(scene->d.rootHi[i]));
-        half[i] = 0.5 * (double(scene->d.rootHi[i]) - double(scene->d.rootLo[i]));
+        centre[i] = 0.5 * (double(boxLo[i]) + double(boxHi[i]));
+        half[i] = 0.5 * (double(boxHi[i]) - double(boxLo[i]));
         half2 += half[i] * half[i];
         extent = std::max(extent, 2.0 * half[i]);
     }
@@ -1857,9 +1871,34 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.cullOn = 0;
     A.cullX0 = A.cullY0 = 0;
     A.cullX1 = A.cullY1 = 0;
+    A.nCutRects = 0;
     if ((driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS) && !f->enable_environment_mapping && scene->d.nSpheres == 0
         && A.unitsPerBlockLog2 >= 0 && !getenv("RTX_NO_CULL"))
-        A.cullOn = cullRectangle(scene, cam, A.W, A.H, A.cullX0, A.cullX1, A.cullY0, A.cullY1) ? 1 : 0;
+    {
+        if (scene->d.rootRef == kEmptyRoot) { // nothing to hit at all
+            A.cullOn = 1;
+            A.cullX0 = A.cullY0 = 1;
+        } else {
+            A.cullOn = cullRectangle(scene->d.rootLo, scene->d.rootHi, cam, A.W, A.H, A.cullX0, A.cullX1, A.cullY0, A.cullY1) ? 1 : 0;
+        }
+        // the finer rectangles; a box that cannot be bounded on the screen (the camera is
+        // inside or beside it) sees every pixel, and then only the root rectangle counts
+        if (A.cullOn && !getenv("RTX_NO_FINE_CULL")) {
+            bool bounded = true;
+            for (const auto& box : scene->cutBoxes) {
+                int32_t r[4];
+                if (!cullRectangle(box.data(), box.data() + 3, cam, A.W, A.H, r[0], r[1], r[2], r[3])) {
+                    bounded = false;
+                    break;
+                }
+                if (r[1] < r[0] || r[3] < r[2])
+                    continue; // entirely behind the camera
+                std::memcpy(A.cutRects[A.nCutRects++], r, sizeof(r));
+            }
+            if (!bounded || scene->cutBoxes.size() < 2)
+                A.nCutRects = 0;
+        }
+    }
 
     // skip-ahead tables for the drivers that draw from the sequential engine
     A.jumpX = c->jump;
@@ -2142,6 +2181,43 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     }
     s->device = g_ctx->device;
     s->numLevels = d->num_levels;
+    // A shallow cut through the tree, level by level while it stays within
+    // kMaxCutBoxes: its boxes together hold every triangle.
+    if (d->root_ref >= 0) {
+        struct Entry { int32_t ref; std::array<float, 6> box; };
+        std::vector<Entry> cut;
+        Entry root;
+        root.ref = d->root_ref;
+        for (int i = 0; i < 3; i++)
+            root.box[size_t(i)] = d->root_lo[i], root.box[size_t(3 + i)] = d->root_hi[i];
+        cut.push_back(root);
+        for (;;) {
+            size_t inner = 0;
+            for (const Entry& e : cut)
+                inner += e.ref >= 0;
+            if (inner == 0 || cut.size() + inner > size_t(kMaxCutBoxes))
+                break;
+            std::vector<Entry> next;
+            for (const Entry& e : cut) {
+                if (e.ref < 0) {
+                    next.push_back(e);
+                    continue;
+                }
+                const rtx_node& n = d->nodes[e.ref];
+                Entry a, b;
+                a.ref = n.ref0, b.ref = n.ref1;
+                for (int i = 0; i < 3; i++) {
+                    a.box[size_t(i)] = n.lo0[i], a.box[size_t(3 + i)] = n.hi0[i];
+                    b.box[size_t(i)] = n.lo1[i], b.box[size_t(3 + i)] = n.hi1[i];
+                }
+                next.push_back(a);
+                next.push_back(b);
+            }
+            cut.swap(next);
+        }
+        for (const Entry& e : cut)
+            s->cutBoxes.push_back(e.box);
+    }
     std::vector<int32_t> idOrder(d->n_tris);
     for (uint32_t k = 0; k < d->n_tris; k++)
         idOrder[size_t(d->tris[k].id)] = int32_t(k);
