@@ -1835,8 +1835,25 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // With area lights every shading point costs the wave a traversal step per 64
     // light samples however few camera samples it carries, so a unit holds few
     // pixels: short units balance better and their camera rays are the small part.
-    if (f->enable_soft_shadow && scene->hasAreaLight && A.shadowSamples >= 16)
+    if (f->enable_soft_shadow && scene->hasAreaLight && A.shadowSamples >= 16) {
         A.pixelsPerUnit = std::min(A.pixelsPerUnit, 8);
+        // Under glossy recursion a camera sample walks a tree of up to glossyRays^depth
+        // shading points one after the other (its draws are numbered in that order), and the
+        // lanes of a wave take turns at the cooperative light sampling: the deeper the tree,
+        // the fewer pixels share a wave, so that a frame is not left waiting for a few waves
+        // that hold several deep pixels each.
+        if (f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1) {
+            double tree = 1;
+            for (int i = 0; i < A.depth && tree < 1e6; i++)
+                tree *= A.glossyRays;
+            A.pixelsPerUnit = std::min(A.pixelsPerUnit, tree <= 25 ? 4 : tree <= 125 ? 2 : 1);
+        }
+    }
+    if (const char* e = getenv("RTX_PIXELS_PER_UNIT")) { // diagnostic: 1, 2, 4, ... 64
+        const int v = atoi(e);
+        if (v >= 1 && v <= A.pixelsPerUnit && 64 % v == 0)
+            A.pixelsPerUnit = v;
+    }
     A.rounds = (A.samples + 63) / 64;
     const uint64_t seqPixels = uint64_t(g.tilesMine) * g.ts * g.ts;
     const uint64_t units = (seqPixels + A.pixelsPerUnit - 1) / A.pixelsPerUnit;

@@ -49,6 +49,7 @@ def main():
         ("area light 64, close-up", dict(soft_shadow=1, hard_shadow=0), dict(distance=1.2), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, ray_depth=0), area),
         ("general path 1 spp", dict(recursive=1), dict(), dict(driver=abi.DRIVER_PLAIN, ray_depth=0), None),
         ("area 64 + glossy depth 2", dict(soft_shadow=1, hard_shadow=0, recursive=1, glossy_reflection=1), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=2), area),
+        ("area 64 + glossy depth 4", dict(soft_shadow=1, hard_shadow=0, recursive=1, glossy_reflection=1), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=4), area),
         ("mirror depth 4", dict(recursive=1), dict(), dict(driver=abi.DRIVER_PLAIN, ray_depth=4), None),
         ("transparency driver", dict(), dict(), dict(driver=abi.DRIVER_TRANSPARENCY), None),
         ("dof 16 samples", dict(), dict(), dict(driver=abi.DRIVER_DOF, samples=16), None),
