@@ -441,3 +441,28 @@ def test_dragon_standin_full_size_properties(gpu_device):
     assert ties == 0
     orc.close()
     gpu.close()
+
+
+def test_multi_rank_code_path_through_rccl_on_one_gpu(gpu_device):
+    """bench.py's N > 1 path (this rank's tiles -> RCCL gather on the collective's
+    stream, overlapped with the next frame's render -> de-tiling) run as a one-rank
+    group on one GPU: the assembled frame must be the single-GPU frame, bit for bit."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-pipeline", "--check", "--no-cpu-baseline",
+                        "--steps", "5", "--warmup", "2", "--width", "640", "--height", "360"],
+                       capture_output=True, text=True, timeout=110, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "check ok" in r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["partition"].startswith("interleaved") and line["value"] > 0
