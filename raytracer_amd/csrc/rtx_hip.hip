@@ -434,11 +434,14 @@ struct Frame { // one suspended getFinalColor call (src/render.cpp:16-66)
     float blur;
     int32_t count, child, nChildren;
     uint32_t rngBase;
+    int32_t traced; // the fan's rays have been traced ahead (fanT / fanK / fanSphere / fanSphereN hold their hits)
 };
 
-enum PathState { PS_DONE = 0, PS_RADIANCE = 1, PS_SHADOW = 2, PS_AREA = 3, PS_ENV = 4 };
+enum PathState { PS_DONE = 0, PS_RADIANCE = 1, PS_SHADOW = 2, PS_AREA = 3, PS_ENV = 4, PS_FAN = 5 };
+constexpr int kFanMax = 8; // glossy fans of up to this many rays are traced by the wave's lanes side by side
 enum Phase { PH_NONE = -1, PH_NEXT_LIGHT, PH_ENV, PH_AFTER_LIGHTS, PH_NEXT_CHILD, PH_RETURN };
 
+RTX_DEV int lane0() { return int(threadIdx.x & 63u); }
 RTX_DEV float laneValue(float v, int srcLane) { return __shfl(v, srcLane, 64); }
 RTX_DEV V3 laneValue(V3 v, int srcLane) { return mk(__shfl(v.x, srcLane, 64), __shfl(v.y, srcLane, 64), __shfl(v.z, srcLane, 64)); }
 
@@ -456,7 +459,7 @@ RTX_DEV V3 laneValue(V3 v, int srcLane) { return mk(__shfl(v.x, srcLane, 64), __
 // contributions are added up in sample order along the lanes and handed back.
 // A path's long sequential run of shadow samples thus becomes one traversal step
 // of a full wave, however few lanes of the wave have a shading point.
-template <int STACK, bool COUNT, bool FULL, bool ENVL = false>
+template <int STACK, bool COUNT, bool FULL, bool ENVL = false, bool FAN = false>
 RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD, bool active, uint32_t rngKey, LaneCounters& lc, float firstLimit = kFltMax)
 {
     const DScene& sc = A.sc;
@@ -476,6 +479,24 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     int li = 0;
 
     Frame frames[FULL ? kMaxDepth : 1];
+    // Glossy fans traced ahead.  The rays of a fan are all drawn before the first of them
+    // is followed (src/shading.cpp:98-105), so their closest hits do not depend on anything
+    // the recursion does in between: a lane that has drawn a fan parks in PS_FAN, the next
+    // iteration is a cooperative one in which the wave's lanes each trace one ray of that
+    // lane's fan, and the hits are handed back.  The lane then follows its children one
+    // after the other as before (their draws are numbered along that walk), but each
+    // child's own traversal is already done.  What a deep glossy path costs per shading
+    // point falls from glossyRays traversals one after the other to one.
+    // (compiled in only for FAN: the storage costs the other paths registers)
+    float fanT[FAN ? kMaxDepth : 1][FAN ? kFanMax : 1];
+    int32_t fanK[FAN ? kMaxDepth : 1][FAN ? kFanMax : 1], fanSphere[FAN ? kMaxDepth : 1][FAN ? kFanMax : 1];
+    V3 fanSphereN[FAN ? kMaxDepth : 1][FAN ? kFanMax : 1];
+    bool preTraced = false; // the radiance ray in flight was traced ahead: pre* hold its hit
+    float preT = kFltMax;
+    int32_t preK = -1, preSphere = -1;
+    V3 preSphereN = mk(0, 0, 0);
+    const int fanGroup = min(max(A.glossyRays, 1), kFanMax), fanPerRound = 64 / fanGroup;
+    const int fanSlot = lane0() / fanGroup, fanChild = lane0() - fanSlot * fanGroup;
     // transparency chain (src/transparency.cpp:6-20): alpha and colour of each
     // layer in front of the last one
     float layerAlpha[FULL ? kMaxLayers : 1];
@@ -514,6 +535,8 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     while (__any(state != PS_DONE)) {
         const uint64_t pending = FULL ? __ballot(state == PS_AREA) : 0ull;
         const bool coop = pending != 0;
+        const uint64_t pendingFan = (FAN && !coop) ? __ballot(state == PS_FAN) : 0ull;
+        const bool coopFan = pendingFan != 0;
         lc.countShaded(shadedPending);
         shadedPending = false;
 
@@ -574,13 +597,45 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                 qStop = shorten ? 1.0f - 4e-3f / len : -__builtin_inff();
                 trace = !workerBehind;
             }
+        } else if (FAN && coopFan) {
+            // lane = one ray of a parked lane's fan (returnGlossyRay, src/shading.cpp:67-88)
+            int mine = -1;
+            uint64_t m = pendingFan;
+            for (int slot = 0; slot < fanPerRound && m; slot++) {
+                const int p = __builtin_ctzll(m);
+                m &= m - 1;
+                served |= 1ull << p;
+                if (fanSlot == slot)
+                    mine = p;
+            }
+            const int src = mine >= 0 ? mine : 0;
+            const Frame& own = frames[level > 0 ? level - 1 : 0]; // (a parked lane's fan is its innermost frame)
+            const V3 fD = laneValue(own.reflD, src), fO = laneValue(own.reflO, src), fN = laneValue(own.nrm, src);
+            const float fBlur = laneValue(own.blur, src);
+            const uint32_t fBase = uint32_t(__shfl(int(own.rngBase), src, 64)), fKey = uint32_t(__shfl(int(rngKey), src, 64));
+            const int fCount = __shfl(own.nChildren, src, 64);
+            worker = mine >= 0 && fanChild < fCount;
+            if (worker) {
+                const V3 w = normalize(fD);
+                const V3 tt = normalize(w - mk(0.1f, 0.0f, 0.0f));
+                const V3 u = normalize(cross(tt, w));
+                const V3 v = normalize(cross(w, u));
+                const float ua = -fBlur / 2.0f + fBlur * keyedUniform(fKey, fBase + 2u * uint32_t(fanChild));
+                const float va = -fBlur / 2.0f + fBlur * keyedUniform(fKey, fBase + 2u * uint32_t(fanChild) + 1u);
+                const V3 dir = fD + (ua * u + va * v);
+                const float cosinus = dot(normalize(dir), fN);
+                const float sinus = __builtin_sqrtf(1.0f - cosinus * cosinus);
+                qo = fO;
+                qd = dir;
+                trace = cosinus > 0.0f && sinus > 0.0f; // the others are never followed (src/render.cpp:31-38)
+            }
         } else {
             if (firstQuery)
                 t = firstLimit;
             lc.countShadow(state == PS_SHADOW || state == PS_ENV);
             lc.countPrimary(state == PS_RADIANCE && level == 0);
             lc.countBounce(state == PS_RADIANCE && level != 0);
-            trace = state == PS_RADIANCE || state == PS_ENV || (state == PS_SHADOW && !shadowBehind);
+            trace = (state == PS_RADIANCE && !(FAN && preTraced)) || state == PS_ENV || (state == PS_SHADOW && !shadowBehind);
             if (state == PS_SHADOW) {
                 qStop = shadowStop;
                 qLimit = shadowLimit;
@@ -593,12 +648,20 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
         // ---- the one traversal site
         Hit hit;
         bool any = false;
+        int bestK = -1, sphere = -1;
+        V3 sphereN = mk(0, 0, 0);
         {
-            int bestK = -1, sphere = -1;
-            V3 sphereN = mk(0, 0, 0);
             if (trace)
                 any = closestHit<STACK, COUNT, true>(sc, st, f, qo, qd, t, bestK, sphere, sphereN, lc.tc, qStop, qLimit);
-            if (!coop && state == PS_RADIANCE)
+            if (FAN && !coop && !coopFan && state == PS_RADIANCE && preTraced) {
+                t = preT;
+                bestK = preK;
+                sphere = preSphere;
+                sphereN = preSphereN;
+                any = bestK >= 0 || sphere >= 0;
+                preTraced = false;
+            }
+            if (!coop && !coopFan && state == PS_RADIANCE)
                 hitAttributes(sc, f, ro, rd, t, bestK, sphere, sphereN, hit);
         }
 
@@ -638,6 +701,28 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                 }
                 areaRound = 0;
                 areaCarry = mk(0, 0, 0);
+            }
+        } else if (FAN && coopFan) {
+            // the k-th served lane finds ray j of its fan in lane k * fanGroup + j
+            const int k = __popcll(served & ((1ull << lane) - 1ull));
+            const bool mineServed = (served >> lane) & 1ull;
+            const int lv = level > 0 ? level - 1 : 0;
+            for (int j = 0; j < fanGroup; j++) {
+                const int from = min(k * fanGroup + j, 63);
+                const float jt = __shfl(t, from, 64);
+                const int jk = __shfl(bestK, from, 64), js = __shfl(sphere, from, 64);
+                const V3 jn = laneValue(sphereN, from);
+                if (mineServed) {
+                    fanT[lv][j] = jt;
+                    fanK[lv][j] = jk;
+                    fanSphere[lv][j] = js;
+                    fanSphereN[lv][j] = jn;
+                }
+            }
+            if (mineServed) {
+                frames[lv].traced = 1;
+                state = PS_RADIANCE; // left again below
+                phase = PH_NEXT_CHILD;
             }
         } else if (state == PS_SHADOW) {
             // testVisibilityLightSample, src/light.cpp:70-102: the shadow ray runs
@@ -818,9 +903,15 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                         F.blur = 0.f;
                         F.rngBase = 0;
                     }
+                    F.traced = 0;
                     level++;
                     depthLeft--;
                     phase = PH_NEXT_CHILD;
+                    if (FAN && f.enable_glossy_reflection && F.nChildren > 1 && F.nChildren <= kFanMax) {
+                        state = PS_FAN; // traced by the whole wave in the next iteration
+                        launched = true;
+                        break;
+                    }
                 }
             }
             if (phase == PH_NEXT_CHILD) {
@@ -845,6 +936,13 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                     if (cosinus > 0.0f && sinus > 0.0f) {
                         ro = F.reflO;
                         rd = dir;
+                        if (FAN && F.traced) {
+                            preTraced = true;
+                            preT = fanT[level - 1][k];
+                            preK = fanK[level - 1][k];
+                            preSphere = fanSphere[level - 1][k];
+                            preSphereN = fanSphereN[level - 1][k];
+                        }
                         state = PS_RADIANCE;
                         launched = true;
                         exhausted = false;
@@ -947,7 +1045,8 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
 }
 
 // MODE 0: point lights + hard shadows only (tracePathLean); 1: the general path;
-// 2: the general path with environment light sampling
+// 2: the general path with environment light sampling; 3: the general path with
+// glossy fans traced by the wave's lanes side by side
 template <int STACK, bool COUNT, int MODE>
 __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES) renderKernel(RenderArgs A)
 {
@@ -1095,7 +1194,7 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                     }
                 }
             }
-            const V3 c = FULL ? tracePath<STACK, COUNT, true, MODE == 2>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT>(A, st, o, d, active, lc);
+            const V3 c = FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
             } else {
@@ -1536,14 +1635,18 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode)
         hipLaunchKernelGGL((renderKernel<STACK, CNT, MODEV>), dim3(grid), dim3(kBlock), 0, c->stream, A);         \
     }
     if (count) {
-        if (mode == 2)
+        if (mode == 3)
+            RTX_LAUNCH(true, 3)
+        else if (mode == 2)
             RTX_LAUNCH(true, 2)
         else if (mode == 1)
             RTX_LAUNCH(true, 1)
         else
             RTX_LAUNCH(true, 0)
     } else {
-        if (mode == 2)
+        if (mode == 3)
+            RTX_LAUNCH(false, 3)
+        else if (mode == 2)
             RTX_LAUNCH(false, 2)
         else if (mode == 1)
             RTX_LAUNCH(false, 1)
@@ -1869,7 +1972,11 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // texture / environment machinery; the lean one is enough otherwise
     const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || driver == RTX_DRIVER_TRANSPARENCY
         || driver == RTX_DRIVER_MOTION_BLUR; // per-sample cameras need device trigonometry
-    const int mode = !full ? 0 : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : 1;
+    // (glossy fans are traced side by side where a wave holds few pixels, i.e. under area
+    // lights: with a full wave of paths the lanes' own traversals already run side by side)
+    const bool fans = f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1 && A.glossyRays <= kFanMax
+        && A.pixelsPerUnit * A.lanesPerPixel <= 8 && !getenv("RTX_NO_FANS");
+    const int mode = !full ? 0 : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
 
     // wave-uniform block arithmetic and the culling rectangle
     A.unitsPerBlockLog2 = -1;

@@ -156,6 +156,34 @@ def test_area_light_sample_counts(gpu_device, samples):
     orc.close()
 
 
+@pytest.mark.parametrize("glossy_rays,depth", [(2, 4), (5, 3), (8, 2), (9, 2)])
+def test_glossy_fans_traced_side_by_side(gpu_device, glossy_rays, depth, monkeypatch):
+    """Under area lights a wave holds few pixels and traces the rays of a glossy fan (up to
+    8) on its lanes side by side before the recursion follows them one by one; larger fans
+    are followed the plain way.  Frame and ray counts must be the oracle's, and the frame
+    must not depend on which of the two ways was taken."""
+    scene = cases.load_scene("cornell")
+    scene.lights = [abi.point_light((0.0, 0.5, 0.3), (0.3, 0.3, 0.3))] + list(cases._AREA)
+    for m in scene.meshes:   # every surface glossy, so that the trees are deep
+        m.material[3:6] = 0.4
+        m.material[6] = 20.0
+    f = abi.features(**dict(cases.BASE, soft_shadow=1, recursive=1, glossy_reflection=1))
+    cam = make_camera()
+    rp = make_params(20, 16, shadow_samples=16, glossy_rays=glossy_rays, ray_depth=depth)
+    gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+    got = gpu.render(cam, f, rp)
+    rays_gpu = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
+    want = orc.render(cam, f, rp)
+    assert rays_gpu == tuple(int(x) for x in orc.counters[:3])
+    assert rays_gpu[2] > 20 * 16          # the recursion did go deep
+    assert_images_close(got, want, f"fans of {glossy_rays}, depth {depth}")
+    monkeypatch.setenv("RTX_NO_FANS", "1")
+    plain = gpu.render(cam, f, rp)
+    assert np.array_equal(np.isnan(plain), np.isnan(got)) and np.array_equal(np.nan_to_num(plain), np.nan_to_num(got))
+    gpu.close()
+    orc.close()
+
+
 def test_shadow_query_shortcuts_do_not_change_frames(gpu_device):
     """The shortened shadow queries must give the reference's answer in the regimes
     where they switch on and off: light closer than 0.2 to surfaces, coordinates
