@@ -52,8 +52,13 @@ struct Ray {
 
 // --------------------------------------------------------- device scene -----
 struct DScene {
-    const float4* nodes;     // 4 x float4 per rtx_node
-    const float4* tris;      // 4 x float4 per rtx_tri (leaf order)
+    // Node and triangle records live in ONE array, nodes first: record r of a child
+    // reference is r itself for an inner node and ~r for a triangle (the device's
+    // references are made at upload: leaf k of the flattened tree is ~(nNodes + k)), so
+    // the traversal finds a lane's next record, whichever kind, with two instructions.
+    const float4* nodes;     // 4 x float4 per rtx_node; the array's start
+    const float4* tris;      // 4 x float4 per rtx_tri (leaf order) = nodes + 4 * nNodes
+    int32_t nNodes;
     const float4* attrs;     // 4 x float4 per rtx_tri_attr
     const int32_t* idOrder;  // leaf-order record index of triangle id i (brute-force path)
     const rtx_material* mats;
@@ -373,7 +378,8 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
         tc.waveOuter += uint32_t(__builtin_ctzll(__ballot(1))) == (threadIdx.x & 63u);
 #endif
         const bool isNode = cur >= 0;
-        const float4* p = isNode ? sc.nodes + size_t(cur) * 4 : sc.tris + size_t(~cur) * 4;
+        const uint32_t record = uint32_t(cur ^ (cur >> 31)); // cur or ~cur
+        const float4* p = sc.nodes + size_t(record) * 4;
         const float4 X = p[0], Y = p[1], Z = p[2], W = p[3];
         bool popNext = true;
         if (isNode) {
@@ -407,7 +413,7 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
             float th;
             if (triangleTestPacked(X, Y, Z, W.x, o, d, t, th)) {
                 t = th;
-                bestK = ~cur;
+                bestK = int(record) - sc.nNodes;
                 if (EARLY && t < tStop)
                     return;
             }

@@ -2358,7 +2358,12 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
             o[4 * ax + 0] = a.lo0[ax], o[4 * ax + 1] = a.lo1[ax];
             o[4 * ax + 2] = a.hi0[ax], o[4 * ax + 3] = a.hi1[ax];
         }
-        std::memcpy(o + 12, &a.ref0, 16);
+        // the device's references: triangle records follow the node records in one array
+        int32_t refs[4] = { a.ref0, a.ref1, a.cnt0, a.cnt1 };
+        for (int c = 0; c < 2; c++)
+            if (refs[c] < 0)
+                refs[c] = ~int32_t(d->n_nodes + uint32_t(~refs[c]));
+        std::memcpy(o + 12, refs, 16);
     }
     std::vector<rtx_tri> packedTris(d->n_tris);
     for (uint32_t i = 0; i < d->n_tris; i++) {
@@ -2370,8 +2375,14 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
         }
         std::memcpy(o + 12, &a.d, 16);
     }
-    int rc = upload(s, packedNodes.data(), d->n_nodes, &nodes);
-    rc = rc ? rc : upload(s, packedTris.data(), d->n_tris, &tris);
+    static_assert(sizeof(rtx_node) == 64 && sizeof(rtx_tri) == 64, "one record size");
+    std::vector<rtx_node> records(size_t(d->n_nodes) + size_t(d->n_tris));
+    if (d->n_nodes)
+        std::memcpy(records.data(), packedNodes.data(), size_t(d->n_nodes) * sizeof(rtx_node));
+    if (d->n_tris)
+        std::memcpy(records.data() + d->n_nodes, packedTris.data(), size_t(d->n_tris) * sizeof(rtx_tri));
+    int rc = upload(s, records.data(), records.size(), &nodes);
+    tris = reinterpret_cast<const rtx_tri*>(nodes ? nodes + d->n_nodes : nullptr);
     rc = rc ? rc : upload(s, d->tri_attrs, d->n_tris, &attrs);
     rc = rc ? rc : upload(s, idOrder.data(), idOrder.size(), &s->d.idOrder);
     rc = rc ? rc : upload(s, d->materials, d->n_materials, &s->d.mats);
@@ -2390,6 +2401,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     s->d.tris = reinterpret_cast<const float4*>(tris);
     s->d.attrs = reinterpret_cast<const float4*>(attrs);
     s->d.env = d->envmap;
+    s->d.nNodes = int32_t(d->n_nodes);
     s->d.nTris = int32_t(d->n_tris);
     s->d.nLights = int32_t(d->n_lights);
     s->d.nEnvBins = int32_t(d->n_env_bins);
@@ -2397,7 +2409,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
         s->hasAreaLight = s->hasAreaLight || d->lights[i].type != RTX_LIGHT_POINT;
     s->d.nSpheres = int32_t(d->n_spheres);
     s->d.nMaterials = int32_t(d->n_materials);
-    s->d.rootRef = d->root_ref;
+    s->d.rootRef = (d->root_ref < 0 && d->root_ref != kEmptyRoot) ? ~int32_t(d->n_nodes + uint32_t(~d->root_ref)) : d->root_ref;
     memcpy(s->d.rootLo, d->root_lo, sizeof(s->d.rootLo));
     memcpy(s->d.rootHi, d->root_hi, sizeof(s->d.rootHi));
     return s;
