@@ -283,7 +283,7 @@ struct TriRec {
     int32_t id, material, flags;
 };
 // The device's triangle record (64 B, leaf order): X = (v0.x, v1.x, v2.x, n.x),
-// Y and Z likewise, W = (D, id, material, flags) -- rtx_tri transposed at upload
+// Y and Z likewise, W = (D, id | last-in-leaf << 31, material, flags) -- rtx_tri transposed at upload
 // so that the pairs the packed test works on are neighbours.
 RTX_DEV TriRec loadTri(const DScene& sc, int k)
 {
@@ -295,7 +295,7 @@ RTX_DEV TriRec loadTri(const DScene& sc, int k)
     r.v2 = mk(X.z, Y.z, Z.z);
     r.n = mk(X.w, Y.w, Z.w);
     r.d = W.x;
-    r.id = __float_as_int(W.y);
+    r.id = __float_as_int(W.y) & 0x7fffffff; // (the top bit marks the last triangle of a leaf)
     r.material = __float_as_int(W.z);
     r.flags = __float_as_int(W.w);
     return r;
@@ -417,7 +417,7 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
                 if (EARLY && t < tStop)
                     return;
             }
-            if (!(__float_as_int(W.w) & RTX_TRI_LAST_IN_LEAF)) {
+            if (__float_as_int(W.y) >= 0) { // not the leaf's last triangle (top bit of the id word, set at upload)
                 cur--;
                 popNext = false;
             }

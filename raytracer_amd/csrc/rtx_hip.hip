@@ -2374,6 +2374,12 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
             o[4 * ax + 2] = a.v2[ax], o[4 * ax + 3] = a.n[ax];
         }
         std::memcpy(o + 12, &a.d, 16);
+        // the traversal reads "last triangle of its leaf" from the top bit of the id word,
+        // which sits beside D, the one other word of this quarter the triangle test needs
+        if (a.flags & RTX_TRI_LAST_IN_LEAF) {
+            const uint32_t marked = uint32_t(a.id) | 0x80000000u;
+            std::memcpy(o + 13, &marked, 4);
+        }
     }
     static_assert(sizeof(rtx_node) == 64 && sizeof(rtx_tri) == 64, "one record size");
     std::vector<rtx_node> records(size_t(d->n_nodes) + size_t(d->n_tris));
