@@ -256,6 +256,17 @@ def device_camera(cam: abi.Camera, width, height) -> abi.Camera:
     return out
 
 
+def camera_rays(cam: abi.Camera, width, height, step=1):
+    """Trackball::generateRay through the corner of every step-th pixel (the positions
+    renderRayTracing uses, src/render.cpp:76-79), rows bottom-up, as an abi.RAY_DTYPE array."""
+    ys, xs = np.mgrid[0:height:step, 0:width:step]
+    ndc = np.stack([xs.ravel().astype(np.float32) / np.float32(width) * np.float32(2) - np.float32(1),
+                    ys.ravel().astype(np.float32) / np.float32(height) * np.float32(2) - np.float32(1)], 1).astype(np.float32)
+    rays = np.zeros(len(ndc), abi.RAY_DTYPE)
+    host_lib().rtxh_camera_rays(C.byref(cam), int(width), int(height), _ptr(np.ascontiguousarray(ndc)), C.c_int64(len(ndc)), _ptr(rays))
+    return rays
+
+
 def load_obj(path, normalize=False) -> "SceneData":
     """loadMesh (framework/src/mesh.cpp:52-176) through the native host loader:
     the meshes of an OBJ / MTL file (PNG textures decoded) as a SceneData."""

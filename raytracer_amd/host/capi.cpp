@@ -390,6 +390,19 @@ int rtxh_render_named(const void* b, const rtx_camera* cam, const rtx_camera* pr
 // camera as the device receives it (derived fields filled in)
 void rtxh_camera(const rtx_camera* cam, int W, int H, rtx_camera* out) { *out = toTrackball(cam, W, H).deviceCamera(); }
 
+// Trackball::generateRay (framework/src/trackball.cpp:101-110) for n normalised pixel
+// positions (x, y in [-1, 1], y up): the camera rays a caller hands to rtxh_intersect_batch
+void rtxh_camera_rays(const rtx_camera* cam, int W, int H, const float* ndc, int64_t n, rtx_ray* out)
+{
+    const Trackball camera = toTrackball(cam, W, H);
+    for (int64_t i = 0; i < n; i++) {
+        const Ray r = camera.generateRay(vec2 { ndc[2 * i], ndc[2 * i + 1] });
+        out[i].origin[0] = r.origin.x, out[i].origin[1] = r.origin.y, out[i].origin[2] = r.origin.z;
+        out[i].direction[0] = r.direction.x, out[i].direction[1] = r.direction.y, out[i].direction[2] = r.direction.z;
+        out[i].t = r.t;
+    }
+}
+
 void rtxh_set_sampling(int shadowSamples, int glossyRays, uint32_t seed)
 {
     if (shadowSamples > 0)

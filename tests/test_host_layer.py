@@ -270,3 +270,14 @@ else:
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "LOUD" in out.stdout or "GPU present" in out.stdout
+
+
+@pytest.mark.parametrize("camera", [dict(), dict(distance=1.2, rotation_degrees=(35, -50, 10)), dict(fov_degrees=100.0, look_at=(0.3, -0.2, 0.1))])
+def test_host_camera_rays_are_the_reference_rays(camera):
+    """Trackball::generateRay of the host layer (framework/src/trackball.cpp:101-110) gives,
+    bit for bit, the rays of the CPU restatement that the golden fixtures pin."""
+    from oracle.bindings import primary_rays
+    cam = make_camera(**camera)
+    got, want = engine.camera_rays(cam, 96, 54, step=5), primary_rays(cam, 96, 54, step=5)
+    assert got.dtype == want.dtype and len(got) == len(want) > 0
+    assert got.tobytes() == want.tobytes()

@@ -16,13 +16,12 @@ def main():
     import torch
     from raytracer_amd import abi, engine
     from raytracer_amd.scene import dragon_scene, make_camera
-    from oracle.bindings import primary_rays
     hip = engine.hip_lib()
     f = abi.features(accel_structure=1, bvh_sah_binning=1, normal_interp=1)
     gpu = engine.GpuEngine(dragon_scene(), f)
     dev = torch.device("cuda", 0)
     for tag, cam in (("headline view", make_camera()), ("close-up d=1.2", make_camera(distance=1.2))):
-        rays = primary_rays(cam, 1920, 1080)
+        rays = engine.camera_rays(cam, 1920, 1080)
         # pixel order -> 8x8 blocks, as a renderer would hand them over
         idx = np.arange(1920 * 1080).reshape(1080 // 8, 8, 1920 // 8, 8).transpose(0, 2, 1, 3).ravel()
         for order, r in (("blocked", rays[idx]), ("shuffled", rays[np.random.default_rng(1).permutation(len(rays))])):
