@@ -2066,12 +2066,17 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.costFloor = 0;
     if (A.unitsPerBlockLog2 >= 0 && A.blocksMine > 1 && A.blocksMine <= uint32_t(kMaxOrderedBlocks) && !getenv("RTX_NO_BLOCK_ORDER")) {
         A.blockCost = c->blockCost;
-        ordered = !(c->costW != A.W || c->costH != A.H || c->costTile != g.ts || c->costRank != g.rank || c->costWorld != g.world || c->costDriver != driver);
-        if (!ordered) {
-            // nothing measured yet for frames of this shape: this one runs in list order
+        const bool measured = !(c->costW != A.W || c->costH != A.H || c->costTile != g.ts || c->costRank != g.rank || c->costWorld != g.world || c->costDriver != driver);
+        if (!measured) {
+            // Nothing measured yet for frames of this shape.  Where blocks can be told
+            // unable to see the scene the frame is ordered all the same (every other block
+            // counts as never measured, i.e. expensive, and keeps its place in the list),
+            // so that those blocks stay out of the queue; otherwise it runs in list order.
             HIP_TRY(hipMemsetAsync(c->blockCost, 0, size_t(A.costStride) * 64 * sizeof(uint32_t), c->stream));
             c->costW = A.W, c->costH = A.H, c->costTile = g.ts, c->costRank = g.rank, c->costWorld = g.world, c->costDriver = driver;
-        } else {
+        }
+        ordered = measured || A.cullOn;
+        if (ordered) {
             auto envClass = [](const char* name, uint32_t fallback) { const char* e = getenv(name); return e ? uint32_t(atoi(e)) : fallback; };
             const uint32_t nSteps = (A.blocksMine + 63u) / 64u, groups = (A.blocksMine + 255u) / 256u;
             hipLaunchKernelGGL(classifyBlocksKernel, dim3(groups), dim3(256), 0, c->stream, A, c->blockClass, c->classTable, nSteps, c->tickets, uint32_t((kTicketBytes + kStatBytes) / sizeof(uint32_t)));
