@@ -1812,7 +1812,13 @@ FastDiv makeFastDiv(uint32_t d)
 // far beyond what rounding in the reference's slab test could bridge, so it misses
 // the root box there too and the pixel is black.  Returns false when no such
 // statement can be made (camera inside the bounds).
-bool cullRectangle(const float* boxLo, const float* boxHi, const rtx_camera* cam, int W, int H, int32_t& x0, int32_t& x1, int32_t& y0, int32_t& y1)
+// `lens` > 0 (depth of field, src/dof.cpp:9-39): a sample's ray starts up to `lens` from the
+// camera position and runs through the point at distance `focal` on the pixel's central ray,
+// so at distance s along the central ray it is at most lens * |1 - s / focal| away from it:
+// the box is grown by the largest such distance over its depth range, and a central ray that
+// misses the grown box has no sample ray that touches the box itself.
+bool cullRectangle(const float* boxLo, const float* boxHi, const rtx_camera* cam, int W, int H, int32_t& x0, int32_t& x1, int32_t& y0, int32_t& y1, double lens = 0.0,
+    double focal = 1.0)
 {
     // world -> camera space: the conjugate of the camera's rotation applied to p - position
     const double qw = cam->quat[0], qx = -cam->quat[1], qy = -cam->quat[2], qz = -cam->quat[3];
@@ -1836,7 +1842,14 @@ bool cullRectangle(const float* boxLo, const float* boxHi, const rtx_camera* cam
         return false;
     // slopes x/z, y/z of the rays that can touch the bounds
     double sLo[2] = { -INFINITY, -INFINITY }, sHi[2] = { INFINITY, INFINITY };
-    const double grow = 1e-3 * (extent + dist) + 1e-6;
+    double grow = 1e-3 * (extent + dist) + 1e-6;
+    if (lens > 0.0) {
+        const double far = dist + std::sqrt(half2);
+        grow += 1.001 * lens * std::max(1.0, far / focal - 1.0);
+        half2 = 0;
+        for (int i = 0; i < 3; i++) // (the sphere fallback below uses the grown half extents)
+            half2 += (half[i] + grow) * (half[i] + grow);
+    }
     bool inFront = true;
     double lo2[2] = { INFINITY, INFINITY }, hi2[2] = { -INFINITY, -INFINITY };
     for (int corner = 0; corner < 8 && inFront; corner++) {
@@ -1996,14 +2009,16 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.cullX0 = A.cullY0 = 0;
     A.cullX1 = A.cullY1 = 0;
     A.nCutRects = 0;
-    if ((driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS) && !f->enable_environment_mapping && scene->d.nSpheres == 0
+    // (depth of field: sample origins lie within half the diagonal of the aperture cube of the camera position)
+    const double lens = driver == RTX_DRIVER_DOF ? 0.5 * std::sqrt(3.0) * double(A.aperture) * 1.0001 : 0.0, lensFocal = double(A.focal);
+    if ((driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF) && !f->enable_environment_mapping && scene->d.nSpheres == 0
         && A.unitsPerBlockLog2 >= 0 && !getenv("RTX_NO_CULL"))
     {
         if (scene->d.rootRef == kEmptyRoot) { // nothing to hit at all
             A.cullOn = 1;
             A.cullX0 = A.cullY0 = 1;
         } else {
-            A.cullOn = cullRectangle(scene->d.rootLo, scene->d.rootHi, cam, A.W, A.H, A.cullX0, A.cullX1, A.cullY0, A.cullY1) ? 1 : 0;
+            A.cullOn = cullRectangle(scene->d.rootLo, scene->d.rootHi, cam, A.W, A.H, A.cullX0, A.cullX1, A.cullY0, A.cullY1, lens, lensFocal) ? 1 : 0;
         }
         // the finer rectangles; a box that cannot be bounded on the screen (the camera is
         // inside or beside it) sees every pixel, and then only the root rectangle counts
@@ -2011,7 +2026,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
             bool bounded = true;
             for (const auto& box : scene->cutBoxes) {
                 int32_t r[4];
-                if (!cullRectangle(box.data(), box.data() + 3, cam, A.W, A.H, r[0], r[1], r[2], r[3])) {
+                if (!cullRectangle(box.data(), box.data() + 3, cam, A.W, A.H, r[0], r[1], r[2], r[3], lens, lensFocal)) {
                     bounded = false;
                     break;
                 }

@@ -217,7 +217,10 @@ def test_blocks_that_cannot_see_the_scene_are_skipped_correctly(gpu_device, came
     scene = cases.load_scene("monkey")
     cam = make_camera(**camera)
     for feat, rp in ((dict(cases.BASE), make_params(120, 72, driver=abi.DRIVER_MRAYS, samples=4)),
-                     (dict(cases.BASE, recursive=1), make_params(97, 61))):
+                     (dict(cases.BASE, recursive=1), make_params(97, 61)),
+                     # depth of field: the samples' origins are spread around the camera position
+                     (dict(cases.BASE), make_params(88, 56, driver=abi.DRIVER_DOF, samples=4, aperture=0.3, focal_length=1.0)),
+                     (dict(cases.BASE), make_params(64, 40, driver=abi.DRIVER_DOF, samples=16, aperture=0.05, focal_length=4.0))):
         f = abi.features(**feat)
         gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
         want = orc.render(cam, f, rp)
