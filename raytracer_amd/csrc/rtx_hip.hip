@@ -1734,7 +1734,8 @@ int traceImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* d
     A.work = makeQueue(c, A.work.nUnits);
     A.stats = c->stats;
     HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (stats)
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
         const bool count = wantCounters();
         switch (stack) {
@@ -1745,7 +1746,8 @@ int traceImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* d
         }
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (stats)
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
     return fetchStats(c, stats, t0);
 }
 
@@ -2106,7 +2108,8 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     }
     if (!ordered)
         HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
-    HIP_TRY(hipEventRecord(c->ev0, c->stream)); // kernel_ms is the render kernel's time
+    if (stats) // (an event record costs the stream a few microseconds around the kernel: only when the time is asked for)
+        HIP_TRY(hipEventRecord(c->ev0, c->stream)); // kernel_ms is the render kernel's time
     if (A.work.nUnits) {
         const bool count = wantCounters();
         switch (stack) {
@@ -2117,7 +2120,8 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         }
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (stats)
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
     return fetchStats(c, stats, t0);
 }
 
@@ -2178,7 +2182,8 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
     S.out = dOut;
     S.n = n;
     HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (stats)
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
         const bool count = wantCounters();
         switch (stack) {
@@ -2189,7 +2194,8 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
         }
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (stats)
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
     return fetchStats(c, stats, t0);
 }
 
