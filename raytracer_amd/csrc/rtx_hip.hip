@@ -1819,8 +1819,12 @@ FastDiv makeFastDiv(uint32_t d)
 // so at distance s along the central ray it is at most lens * |1 - s / focal| away from it:
 // the box is grown by the largest such distance over its depth range, and a central ray that
 // misses the grown box has no sample ray that touches the box itself.
+// `sway`, `turn` > 0 (motion blur, src/render.cpp:203-247, with `cam` the pose halfway through
+// the exposure): a sample's camera stands at most `sway` from that pose's position and its
+// rotation differs by at most `turn` radians, so a point at distance s along a sample's ray is
+// at most sway + s * turn from the halfway pose's ray through the same pixel.
 bool cullRectangle(const float* boxLo, const float* boxHi, const rtx_camera* cam, int W, int H, int32_t& x0, int32_t& x1, int32_t& y0, int32_t& y1, double lens = 0.0,
-    double focal = 1.0)
+    double focal = 1.0, double sway = 0.0, double turn = 0.0)
 {
     // world -> camera space: the conjugate of the camera's rotation applied to p - position
     const double qw = cam->quat[0], qx = -cam->quat[1], qy = -cam->quat[2], qz = -cam->quat[3];
@@ -1845,9 +1849,11 @@ bool cullRectangle(const float* boxLo, const float* boxHi, const rtx_camera* cam
     // slopes x/z, y/z of the rays that can touch the bounds
     double sLo[2] = { -INFINITY, -INFINITY }, sHi[2] = { INFINITY, INFINITY };
     double grow = 1e-3 * (extent + dist) + 1e-6;
-    if (lens > 0.0) {
+    if (lens > 0.0 || sway > 0.0 || turn > 0.0) {
         const double far = dist + std::sqrt(half2);
-        grow += 1.001 * lens * std::max(1.0, far / focal - 1.0);
+        if (lens > 0.0)
+            grow += 1.001 * lens * std::max(1.0, far / focal - 1.0);
+        grow += 1.001 * (sway + (far + sway) * turn);
         half2 = 0;
         for (int i = 0; i < 3; i++) // (the sphere fallback below uses the grown half extents)
             half2 += (half[i] + grow) * (half[i] + grow);
@@ -1950,6 +1956,11 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.out = dOut;
     A.lanesPerPixel = std::min(A.samples, 64);
     A.pixelsPerUnit = 64 / A.lanesPerPixel;
+    // A unit must not straddle 8x8 blocks for the blocks to be ordered and skipped: a
+    // sample count that does not divide 64 (7 blur steps: 9 pixels per wave) gives up
+    // the odd pixel (8 pixels, 56 of 64 lanes).
+    while (64 % A.pixelsPerUnit != 0)
+        A.pixelsPerUnit--;
     // With area lights every shading point costs the wave a traversal step per 64
     // light samples however few camera samples it carries, so a unit holds few
     // pixels: short units balance better and their camera rays are the small part.
@@ -2013,14 +2024,52 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.nCutRects = 0;
     // (depth of field: sample origins lie within half the diagonal of the aperture cube of the camera position)
     const double lens = driver == RTX_DRIVER_DOF ? 0.5 * std::sqrt(3.0) * double(A.aperture) * 1.0001 : 0.0, lensFocal = double(A.focal);
-    if ((driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF) && !f->enable_environment_mapping && scene->d.nSpheres == 0
+    // (motion blur: the samples' poses run from the current one to one full pose change beyond
+    // it; the rectangle is taken from the pose halfway, grown by how far the others stray from it)
+    rtx_camera cullCam = *cam;
+    double sway = 0.0, turn = 0.0;
+    if (driver == RTX_DRIVER_MOTION_BLUR) {
+        double dl = 0, e[3], q[4];
+        for (int i = 0; i < 3; i++) {
+            const double dLook = double(cam->look_at[i]) - double(p->prev_camera.look_at[i]), dEuler = double(cam->euler[i]) - double(p->prev_camera.euler[i]);
+            cullCam.look_at[i] = float(double(cam->look_at[i]) + 0.5 * dLook);
+            e[i] = double(cam->euler[i]) + 0.5 * dEuler;
+            cullCam.euler[i] = float(e[i]);
+            dl += dLook * dLook;
+            turn += 0.5 * std::fabs(dEuler);
+        }
+        const double dDist = double(cam->distance) - double(p->prev_camera.distance), distMid = double(cam->distance) + 0.5 * dDist;
+        cullCam.distance = float(distMid);
+        // glm::quat(euler), glm/detail/type_quat.inl:208-217
+        const double cx = std::cos(0.5 * e[0]), cy = std::cos(0.5 * e[1]), cz = std::cos(0.5 * e[2]), sx = std::sin(0.5 * e[0]), sy = std::sin(0.5 * e[1]), sz = std::sin(0.5 * e[2]);
+        q[0] = cx * cy * cz + sx * sy * sz;
+        q[1] = sx * cy * cz - cx * sy * sz;
+        q[2] = cx * sy * cz + sx * cy * sz;
+        q[3] = cx * cy * sz - sx * sy * cz;
+        // position = lookAt + q * (0, 0, -distance): v + 2 (w (qv x v) + qv x (qv x v))
+        const double v[3] = { 0, 0, -distMid };
+        const double uv[3] = { q[2] * v[2] - q[3] * v[1], q[3] * v[0] - q[1] * v[2], q[1] * v[1] - q[2] * v[0] };
+        const double uuv[3] = { q[2] * uv[2] - q[3] * uv[1], q[3] * uv[0] - q[1] * uv[2], q[1] * uv[1] - q[2] * uv[0] };
+        for (int i = 0; i < 3; i++) {
+            cullCam.position[i] = float(double(cullCam.look_at[i]) + v[i] + 2.0 * (q[0] * uv[i] + uuv[i]));
+            cullCam.quat[i + 1] = float(q[i + 1]);
+        }
+        cullCam.quat[0] = float(q[0]);
+        turn = turn * 1.001 + 1e-5; // (float poses on the device, double here)
+        sway = 0.5 * std::sqrt(dl) + 0.5 * std::fabs(dDist) + (std::fabs(distMid) + 0.5 * std::fabs(dDist)) * turn;
+        sway = sway * 1.001 + 1e-5 * (1.0 + std::fabs(distMid));
+        if (!std::isfinite(sway) || !std::isfinite(turn))
+            sway = turn = INFINITY; // (no rectangle can be bounded then)
+    }
+    const rtx_camera* const cullFrom = &cullCam;
+    if ((driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF || driver == RTX_DRIVER_MOTION_BLUR) && !f->enable_environment_mapping && scene->d.nSpheres == 0
         && A.unitsPerBlockLog2 >= 0 && !getenv("RTX_NO_CULL"))
     {
         if (scene->d.rootRef == kEmptyRoot) { // nothing to hit at all
             A.cullOn = 1;
             A.cullX0 = A.cullY0 = 1;
         } else {
-            A.cullOn = cullRectangle(scene->d.rootLo, scene->d.rootHi, cam, A.W, A.H, A.cullX0, A.cullX1, A.cullY0, A.cullY1, lens, lensFocal) ? 1 : 0;
+            A.cullOn = cullRectangle(scene->d.rootLo, scene->d.rootHi, cullFrom, A.W, A.H, A.cullX0, A.cullX1, A.cullY0, A.cullY1, lens, lensFocal, sway, turn) ? 1 : 0;
         }
         // the finer rectangles; a box that cannot be bounded on the screen (the camera is
         // inside or beside it) sees every pixel, and then only the root rectangle counts
@@ -2028,7 +2077,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
             bool bounded = true;
             for (const auto& box : scene->cutBoxes) {
                 int32_t r[4];
-                if (!cullRectangle(box.data(), box.data() + 3, cam, A.W, A.H, r[0], r[1], r[2], r[3], lens, lensFocal)) {
+                if (!cullRectangle(box.data(), box.data() + 3, cullFrom, A.W, A.H, r[0], r[1], r[2], r[3], lens, lensFocal, sway, turn)) {
                     bounded = false;
                     break;
                 }

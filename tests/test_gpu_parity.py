@@ -216,7 +216,14 @@ def test_blocks_that_cannot_see_the_scene_are_skipped_correctly(gpu_device, came
     touching them, with the scene partly or wholly outside the view, or behind."""
     scene = cases.load_scene("monkey")
     cam = make_camera(**camera)
+    # motion blur: the camera of the call before stood elsewhere, looked elsewhere, was turned
+    rot = camera.get("rotation_degrees", (20, 20, 0))
+    moved = make_camera(**dict(camera, look_at=tuple(np.add(camera.get("look_at", (0, 0, 0)), (0.12, -0.05, 0.2))),
+                               rotation_degrees=(rot[0] + 6, rot[1] - 4, rot[2] + 3), distance=camera.get("distance", 3.0) * 1.07))
+    nudged = make_camera(**dict(camera, rotation_degrees=(rot[0], rot[1] + 1.5, rot[2])))
     for feat, rp in ((dict(cases.BASE), make_params(120, 72, driver=abi.DRIVER_MRAYS, samples=4)),
+                     (dict(cases.BASE), make_params(72, 48, driver=abi.DRIVER_MOTION_BLUR, samples=5, prev_camera=moved)),
+                     (dict(cases.BASE), make_params(64, 40, driver=abi.DRIVER_MOTION_BLUR, samples=7, prev_camera=nudged)),
                      (dict(cases.BASE, recursive=1), make_params(97, 61)),
                      # depth of field: the samples' origins are spread around the camera position
                      (dict(cases.BASE), make_params(88, 56, driver=abi.DRIVER_DOF, samples=4, aperture=0.3, focal_length=1.0)),

@@ -53,6 +53,7 @@ def main():
         ("mirror depth 4", dict(recursive=1), dict(), dict(driver=abi.DRIVER_PLAIN, ray_depth=4), None),
         ("transparency driver", dict(), dict(), dict(driver=abi.DRIVER_TRANSPARENCY), None),
         ("dof 16 samples", dict(), dict(), dict(driver=abi.DRIVER_DOF, samples=16), None),
+        ("motion blur 7 steps", dict(), dict(), dict(driver=abi.DRIVER_MOTION_BLUR, samples=7, prev_camera=engine.device_camera(make_camera(rotation_degrees=(22, 18, 0)), 1920, 1080)), None),
     ]
     only = [s for s in args.only.split(",") if s]
     dev = torch.device("cuda", 0)
