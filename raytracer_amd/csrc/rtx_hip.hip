@@ -2016,8 +2016,9 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.divBlocksPerTile = makeFastDiv(A.blocksPerTile);
     A.divTilesX = makeFastDiv(uint32_t(g.tilesX));
     A.divBlocksPerRow = makeFastDiv(A.blocksPerRow);
-    // One camera position for the whole frame, a miss is black, and nothing but the
-    // BVH's triangles can be hit: then blocks that cannot see the root box are skipped.
+    // A miss is black and nothing but the BVH's triangles can be hit: then blocks whose
+    // camera rays (of every sample: lens positions, poses of the exposure) cannot reach
+    // the root box are skipped.
     A.cullOn = 0;
     A.cullX0 = A.cullY0 = 0;
     A.cullX1 = A.cullY1 = 0;
@@ -2062,7 +2063,9 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
             sway = turn = INFINITY; // (no rectangle can be bounded then)
     }
     const rtx_camera* const cullFrom = &cullCam;
-    if ((driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF || driver == RTX_DRIVER_MOTION_BLUR) && !f->enable_environment_mapping && scene->d.nSpheres == 0
+    // (every driver: a camera ray that misses everything is black in all of them, src/render.cpp:61-64,
+    // src/transparency.cpp:9-11)
+    if (!f->enable_environment_mapping && scene->d.nSpheres == 0
         && A.unitsPerBlockLog2 >= 0 && !getenv("RTX_NO_CULL"))
     {
         if (scene->d.rootRef == kEmptyRoot) { // nothing to hit at all

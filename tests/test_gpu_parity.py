@@ -222,6 +222,7 @@ def test_blocks_that_cannot_see_the_scene_are_skipped_correctly(gpu_device, came
                                rotation_degrees=(rot[0] + 6, rot[1] - 4, rot[2] + 3), distance=camera.get("distance", 3.0) * 1.07))
     nudged = make_camera(**dict(camera, rotation_degrees=(rot[0], rot[1] + 1.5, rot[2])))
     for feat, rp in ((dict(cases.BASE), make_params(120, 72, driver=abi.DRIVER_MRAYS, samples=4)),
+                     (dict(cases.BASE), make_params(90, 50, driver=abi.DRIVER_TRANSPARENCY)),
                      (dict(cases.BASE), make_params(72, 48, driver=abi.DRIVER_MOTION_BLUR, samples=5, prev_camera=moved)),
                      (dict(cases.BASE), make_params(64, 40, driver=abi.DRIVER_MOTION_BLUR, samples=7, prev_camera=nudged)),
                      (dict(cases.BASE, recursive=1), make_params(97, 61)),
