@@ -288,6 +288,14 @@ int rtx_tiles_per_rank(const rtx_render_params* params);
  * with the caller's other work on that stream. */
 int rtx_set_stream(void* hip_stream);
 
+/* Page-locked host memory for buffers that travel to or from the GPU (a framebuffer handed to
+ * rtx_render, ray and hit arrays handed to rtx_trace): copies run at the bus's full rate
+ * instead of through the runtime's staging buffer.  No counterpart in the reference, whose
+ * Screen is plain host memory (src/screen.h:16-33); any host memory is accepted everywhere, this
+ * is only faster.  Needs no rtx_init; returns NULL when no GPU or no such memory is available. */
+void* rtx_host_alloc(size_t bytes);
+void  rtx_host_free(void* buffer);
+
 /* Block until all work queued by this thread's calls has finished. */
 int rtx_synchronize(void);
 

@@ -1508,6 +1508,11 @@ struct DeviceCtx {
     uint32_t* classTable = nullptr;                        // device: kCostClasses x (kMaxOrderedBlocks / 64) words
     uint32_t* queueBounds = nullptr;                      // device: the work queue's plan, written by scanBlocksKernel
     int costW = -1, costH = -1, costTile = -1, costRank = -1, costWorld = -1, costDriver = -1;
+    // device framebuffer behind the host-buffer entry point (rtx_render), kept from call to
+    // call and grown when a larger frame comes; hostFrame serialises its users
+    std::mutex hostFrame;
+    float* frame = nullptr;
+    size_t frameBytes = 0;
 };
 constexpr size_t kTicketBytes = size_t(kQueues) * kQueueStride * sizeof(uint32_t), kStatBytes = size_t(kStatSlots) * kStatStride * sizeof(unsigned long long);
 constexpr int kJumpMaxDim = 32768, kJumpMaxSamples = 4096, kJumpCap = 2 * kJumpMaxDim + kJumpMaxSamples;
@@ -2611,8 +2616,17 @@ int rtx_render(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     if (int rc = tileGeom(p, g))
         return rc;
     const size_t bytes = size_t(p->width) * size_t(p->height) * 3 * sizeof(float);
-    float* dOut = nullptr;
-    HIP_TRY(hipMalloc((void**)&dOut, bytes));
+    DeviceCtx* c = g_ctx;
+    std::lock_guard<std::mutex> frameLock(c->hostFrame);
+    if (c->frameBytes < bytes) {
+        if (c->frame)
+            (void)hipFree(c->frame);
+        c->frame = nullptr;
+        c->frameBytes = 0;
+        HIP_TRY(hipMalloc((void**)&c->frame, bytes));
+        c->frameBytes = bytes;
+    }
+    float* const dOut = c->frame;
     int rc = RTX_OK;
     // pixels of other ranks' tiles keep the caller's values
     if (g.world > 1 && (hipMemcpyAsync(dOut, out, bytes, hipMemcpyHostToDevice, g_ctx->stream) != hipSuccess || hipStreamSynchronize(g_ctx->stream) != hipSuccess)) {
@@ -2624,7 +2638,6 @@ int rtx_render(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         setErr("rtx_render: framebuffer download failed");
         rc = RTX_ERR_DEVICE;
     }
-    (void)hipFree(dOut);
     if (stats)
         stats->total_ms = nowMs() - t0;
     return rc;
@@ -2727,6 +2740,23 @@ int rtx_debug_probe(void* out, size_t nUnits)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), nUnits * sizeof(uint4)) == hipSuccess ? RTX_OK : RTX_ERR_DEVICE;
 }
 #endif
+
+void* rtx_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError(); // (not an error of the path: the caller falls back to plain memory)
+        setErr("rtx_host_alloc: no page-locked memory for %zu bytes", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void rtx_host_free(void* p)
+{
+    if (p && hipHostFree(p) != hipSuccess)
+        (void)hipGetLastError();
+}
 
 int rtx_synchronize(void)
 {

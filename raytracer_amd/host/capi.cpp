@@ -332,11 +332,7 @@ int rtxh_render(const void* b, const rtx_camera* cam, const rtx_features* f, con
 {
     return guarded([&] {
         const auto* bvh = static_cast<const BvhInterface*>(b);
-        Screen screen(ivec2 { rp->width, rp->height });
-        if (rp->tile_world > 1)
-            std::memcpy(static_cast<void*>(screen.pixels().data()), out, size_t(rp->width) * size_t(rp->height) * 12);
-        renderFrame(*bvh, toTrackball(cam, rp->width, rp->height), screen, toFeatures(f), *rp, stats);
-        std::memcpy(out, screen.pixels().data(), size_t(rp->width) * size_t(rp->height) * 12);
+        renderInto(*bvh, toTrackball(cam, rp->width, rp->height), rp->width, rp->height, out, toFeatures(f), *rp, stats);
     });
 }
 

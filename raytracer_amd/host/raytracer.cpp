@@ -3,6 +3,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <new>
+#include <unordered_set>
 
 namespace rt {
 
@@ -209,6 +212,34 @@ Screen::Screen(const ivec2& resolution, bool)
     , m_textureData(size_t(resolution.x) * size_t(resolution.y), vec3(0.0f))
 {
 }
+// Page-locked blocks handed out by pixelStoreAlloc (the others came from operator new)
+namespace {
+std::mutex g_pinnedMutex;
+std::unordered_set<void*> g_pinned;
+}
+void* pixelStoreAlloc(size_t bytes)
+{
+    if (void* p = rtx_host_alloc(bytes)) {
+        std::lock_guard<std::mutex> lock(g_pinnedMutex);
+        g_pinned.insert(p);
+        return p;
+    }
+    return ::operator new(bytes);
+}
+void pixelStoreFree(void* p) noexcept
+{
+    if (!p)
+        return;
+    bool pinned = false;
+    {
+        std::lock_guard<std::mutex> lock(g_pinnedMutex);
+        pinned = g_pinned.erase(p) != 0;
+    }
+    if (pinned)
+        rtx_host_free(p);
+    else
+        ::operator delete(p);
+}
 void Screen::clear(const vec3& color) { std::fill(m_textureData.begin(), m_textureData.end(), color); }
 void Screen::setPixel(int x, int y, const vec3& color) { m_textureData[size_t(indexAt(x, y))] = color; }
 void Screen::writeBitmapToFile(const std::string& filePath) const
@@ -245,21 +276,27 @@ void Screen::writeBitmapToFile(const std::string& filePath) const
 }
 
 // ----------------------------------------------------------------- drivers --
-void renderFrame(const BvhInterface& bvh, const Trackball& camera, Screen& screen, const Features& features, rtx_render_params params, rtx_stats* stats)
+void renderInto(const BvhInterface& bvh, const Trackball& camera, int width, int height, float* rgb, const Features& features, rtx_render_params params, rtx_stats* stats)
 {
     ensureDevice();
-    const ivec2 res = screen.resolution();
-    params.width = res.x;
-    params.height = res.y;
+    params.width = width;
+    params.height = height;
     if (params.shadow_samples <= 0)
         params.shadow_samples = sampleSize;
     if (params.glossy_rays <= 0)
         params.glossy_rays = numberOfRays;
     const rtx_features f = toDeviceFeatures(features);
     const rtx_camera cam = camera.deviceCamera();
-    static_assert(sizeof(vec3) == 12, "vec3 must be three packed floats");
-    if (rtx_render(bvh.deviceScene(), &cam, &f, &params, &screen.pixels()[0].x, stats) != RTX_OK)
+    if (rtx_render(bvh.deviceScene(), &cam, &f, &params, rgb, stats) != RTX_OK)
         fail("rtx_render");
+}
+
+void renderFrame(const BvhInterface& bvh, const Trackball& camera, Screen& screen, const Features& features, rtx_render_params params, rtx_stats* stats)
+{
+    ensureDevice();
+    const ivec2 res = screen.resolution();
+    static_assert(sizeof(vec3) == 12, "vec3 must be three packed floats");
+    renderInto(bvh, camera, res.x, res.y, &screen.pixels()[0].x, features, params, stats);
 }
 
 namespace {

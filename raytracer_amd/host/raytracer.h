@@ -13,6 +13,7 @@
 #pragma once
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "bvh_build.h"
 #include "rt_types.h"
@@ -93,6 +94,26 @@ private:
     vec3 m_rotationEulerAngles { 0.f, 0.f, 0.f };
 };
 
+// Storage of a Screen's pixels: a std::vector whose memory is page-locked (rtx_host_alloc)
+// where a GPU is present, so that a frame comes back from the device at the bus's full
+// rate, and plain memory otherwise.
+void* pixelStoreAlloc(size_t bytes);
+void pixelStoreFree(void* p) noexcept;
+template <class T>
+struct PixelAllocator {
+    using value_type = T;
+    PixelAllocator() = default;
+    template <class U>
+    PixelAllocator(const PixelAllocator<U>&) noexcept {}
+    T* allocate(size_t n) { return static_cast<T*>(pixelStoreAlloc(n * sizeof(T))); }
+    void deallocate(T* p, size_t) noexcept { pixelStoreFree(p); }
+    template <class U>
+    bool operator==(const PixelAllocator<U>&) const noexcept { return true; }
+    template <class U>
+    bool operator!=(const PixelAllocator<U>&) const noexcept { return false; }
+};
+using PixelStore = std::vector<vec3, PixelAllocator<vec3>>;
+
 // fp32 RGB framebuffer in the reference's layout: row 0 is the top row
 // (src/screen.cpp:37-43).
 class Screen {
@@ -102,14 +123,14 @@ public:
     void setPixel(int x, int y, const vec3& color);
     [[nodiscard]] ivec2 resolution() const { return m_resolution; }
     [[nodiscard]] int indexAt(int x, int y) const { return (m_resolution.y - 1 - y) * m_resolution.x + x; }
-    [[nodiscard]] const std::vector<vec3>& pixels() const { return m_textureData; }
-    [[nodiscard]] std::vector<vec3>& pixels() { return m_textureData; }
+    [[nodiscard]] const PixelStore& pixels() const { return m_textureData; }
+    [[nodiscard]] PixelStore& pixels() { return m_textureData; }
     // 4-channel BMP, clamp then truncate to 8 bits (src/screen.cpp:45-56)
     void writeBitmapToFile(const std::string& filePath) const;
 
 private:
     ivec2 m_resolution;
-    std::vector<vec3> m_textureData;
+    PixelStore m_textureData;
 };
 
 // src/render.h:18-29.  `scene` must be the scene the BvhInterface was built from.
@@ -133,6 +154,8 @@ void getFinalColorBatch(const BvhInterface& bvh, const rtx_ray* rays, size_t n, 
 // (the reference's drivers hard-code 0 or 1), optional interleaved-tile
 // partition, statistics.
 void renderFrame(const BvhInterface& bvh, const Trackball& camera, Screen& screen, const Features& features, rtx_render_params params, rtx_stats* stats = nullptr);
+// The same into a caller's buffer of width x height RGB triplets in Screen layout.
+void renderInto(const BvhInterface& bvh, const Trackball& camera, int width, int height, float* rgb, const Features& features, rtx_render_params params, rtx_stats* stats = nullptr);
 
 rtx_features toDeviceFeatures(const Features& features);
 
