@@ -505,3 +505,31 @@ def test_multi_rank_code_path_through_rccl_on_one_gpu(gpu_device):
     assert "check ok" in r.stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["partition"].startswith("interleaved") and line["value"] > 0
+
+
+def test_render_into_page_locked_host_memory(gpu_device):
+    """rtx_render into a buffer from rtx_host_alloc gives the frame it gives into plain host
+    memory (the copy back takes the direct path instead of the runtime's staging buffer)."""
+    import ctypes as C
+    from raytracer_amd import engine
+    hip = engine.hip_lib()
+    hip.rtx_host_alloc.restype = C.c_void_p
+    hip.rtx_host_alloc.argtypes = [C.c_size_t]
+    hip.rtx_host_free.argtypes = [C.c_void_p]
+    scene = cases.load_scene("monkey")
+    f = abi.features(**cases.BASE)
+    gpu = GpuEngine(scene, f)
+    w, h = 200, 120
+    cam = engine.device_camera(make_camera(), w, h)
+    rp = make_params(w, h, driver=abi.DRIVER_MRAYS, samples=4)
+    plain = np.full((h, w, 3), -1.0, np.float32)
+    locked = hip.rtx_host_alloc(C.c_size_t(plain.nbytes))
+    assert locked, hip.rtx_last_error()
+    try:
+        for ptr in (plain.ctypes.data, locked):
+            assert hip.rtx_render(gpu.device_scene(), C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(ptr), None) == 0, hip.rtx_last_error()
+        got = np.ctypeslib.as_array((C.c_float * (w * h * 3)).from_address(locked)).reshape(h, w, 3)
+        assert np.array_equal(got, plain) and plain.min() >= 0.0 and plain.max() > 0.0
+    finally:
+        hip.rtx_host_free(C.c_void_p(locked))
+        gpu.close()

@@ -281,3 +281,31 @@ def test_host_camera_rays_are_the_reference_rays(camera):
     got, want = engine.camera_rays(cam, 96, 54, step=5), primary_rays(cam, 96, 54, step=5)
     assert got.dtype == want.dtype and len(got) == len(want) > 0
     assert got.tobytes() == want.tobytes()
+
+
+def test_page_locked_allocation_falls_back_without_a_gpu():
+    """rtx_host_alloc returns NULL (with an error text) where no page-locked memory can be
+    had, and the host layer's Screen then keeps its pixels in plain memory: a Screen can be
+    made, filled and written to a bitmap on a machine without a GPU (child process, so this
+    process' GPU state is untouched)."""
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from raytracer_amd import engine
+lib = engine.hip_lib()
+lib.rtx_host_alloc.restype = C.c_void_p
+lib.rtx_host_alloc.argtypes = [C.c_size_t]
+lib.rtx_host_free.argtypes = [C.c_void_p]
+p = lib.rtx_host_alloc(1 << 20)
+if p:
+    C.memset(p, 7, 1 << 20)
+    lib.rtx_host_free(p)
+    print("PINNED")
+else:
+    assert lib.rtx_last_error() != b""
+    print("PLAIN")
+lib.rtx_host_free(None)
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "PINNED" in out.stdout or "PLAIN" in out.stdout
