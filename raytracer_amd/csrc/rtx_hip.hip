@@ -1331,6 +1331,12 @@ __global__ void __launch_bounds__(256) classifyBlocksKernel(RenderArgs A, uint8_
     for (uint32_t w = i; w < clearWords; w += gridDim.x * 256u)
         clear[w] = 0;
     const bool valid = i < A.blocksMine;
+    // (the rectangles are staged in LDS: read one by one from the kernel's arguments
+    // they cost this kernel three times its other work)
+    __shared__ int4 rects[kMaxCutBoxes];
+    if (threadIdx.x < uint32_t(A.nCutRects))
+        rects[threadIdx.x] = make_int4(A.cutRects[threadIdx.x][0], A.cutRects[threadIdx.x][1], A.cutRects[threadIdx.x][2], A.cutRects[threadIdx.x][3]);
+    __syncthreads();
     uint32_t cls = 0;
     if (valid) {
         const BlockPlace b = placeBlock(A, i); // (A.blockOrder is NULL here: list order)
@@ -1338,8 +1344,11 @@ __global__ void __launch_bounds__(256) classifyBlocksKernel(RenderArgs A, uint8_
         if (!empty && A.nCutRects > 0) {
             const int bx0 = int(b.x0), yHigh = A.H - 1 - int(b.y0), yLow = yHigh - 7;
             bool seen = false;
-            for (int r = 0; r < A.nCutRects && !seen; r++)
-                seen = !(bx0 + 7 < A.cutRects[r][0] || bx0 > A.cutRects[r][1] || yHigh < A.cutRects[r][2] || yLow > A.cutRects[r][3]);
+#pragma unroll 8
+            for (int r = 0; r < A.nCutRects; r++) {
+                const int4 q = rects[r];
+                seen = seen || !(bx0 + 7 < q.x || bx0 > q.y || yHigh < q.z || yLow > q.w);
+            }
             empty = !seen;
         }
         uint32_t& mine = A.blockCost[costIndex(A, i)];
