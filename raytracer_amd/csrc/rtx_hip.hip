@@ -1580,6 +1580,8 @@ int upload(rtx_scene* s, const T* src, size_t count, const T** dst)
 int pickStack(int numLevels)
 {
     // nearer-child-first depth-first traversal holds at most one entry per level
+    if (const char* e = getenv("RTX_MIN_STACK")) // diagnostic: run a shallow tree on a deeper stack's kernel
+        numLevels = std::max(numLevels, atoi(e));
     if (numLevels <= 16)
         return 16;
     if (numLevels <= 24)

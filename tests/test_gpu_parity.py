@@ -533,3 +533,48 @@ def test_render_into_page_locked_host_memory(gpu_device):
     finally:
         hip.rtx_host_free(C.c_void_p(locked))
         gpu.close()
+
+
+@pytest.mark.parametrize("min_stack", [24, 32, 64])
+def test_kernels_for_deeper_trees_give_the_same_frames(gpu_device, min_stack, monkeypatch):
+    """The traversal stack is sized by the tree's depth (16, 24, 32 or 64 entries per lane, one
+    kernel build each).  The deeper builds, forced onto a shallow tree, must give the frames,
+    hits and ray counts of the 16-entry one, on the lean and on the general path."""
+    from raytracer_amd import engine
+    scene = cases.load_scene("monkey")
+    cam = make_camera()
+    runs = [(abi.features(**cases.BASE), make_params(96, 64, driver=abi.DRIVER_MRAYS, samples=4)),
+            (abi.features(**dict(cases.BASE, recursive=1)), make_params(80, 60))]
+    gpu = GpuEngine(scene, runs[0][0])
+    rays = engine.camera_rays(cam, 96, 64, step=2)
+    base = [(gpu.render(cam, f, rp), (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)) for f, rp in runs]
+    base_hits = gpu.intersect(rays, runs[0][0])
+    monkeypatch.setenv("RTX_MIN_STACK", str(min_stack))
+    for (f, rp), (want, want_rays) in zip(runs, base):
+        got = gpu.render(cam, f, rp)
+        assert (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce) == want_rays
+        assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want)) and np.array_equal(np.isnan(got), np.isnan(want))
+    assert gpu.intersect(rays, runs[0][0]).tobytes() == base_hits.tobytes()
+    gpu.close()
+
+
+def test_tree_deeper_than_sixteen_levels(gpu_device):
+    """491 520 triangles give the reference's builder 17 levels, i.e. the 24-entry stack: frame
+    and primary hits against the oracle."""
+    from raytracer_amd import engine
+    from raytracer_amd.scene import instanced_scene
+    scene = instanced_scene(6)
+    f = abi.features(**cases.BASE)
+    gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+    assert gpu.levels() > 16
+    cam = make_camera()
+    rp = make_params(96, 54, driver=abi.DRIVER_MRAYS, samples=4)
+    got = gpu.render(cam, f, rp)
+    rays_gpu = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
+    want = orc.render(cam, f, rp)
+    assert rays_gpu == tuple(int(x) for x in orc.counters[:3])
+    assert_images_close(got, want, "six instances, 17 levels")
+    rays = engine.camera_rays(cam, 192, 108, step=3)
+    assert_hits_equal(gpu.intersect(rays, f), orc.intersect(rays, f), "six instances, primary rays")
+    gpu.close()
+    orc.close()
