@@ -578,3 +578,24 @@ def test_tree_deeper_than_sixteen_levels(gpu_device):
     assert_hits_equal(gpu.intersect(rays, f), orc.intersect(rays, f), "six instances, primary rays")
     gpu.close()
     orc.close()
+
+
+def test_counting_kernel_builds_give_the_same_frames(gpu_device, monkeypatch):
+    """With RTX_COUNT_TESTS the kernels that also count box and triangle tests run: same
+    frames and ray counts, and the counts are reported."""
+    scene = cases.load_scene("monkey")
+    cam = make_camera()
+    runs = [(abi.features(**cases.BASE), make_params(96, 64, driver=abi.DRIVER_MRAYS, samples=4)),
+            (abi.features(**dict(cases.BASE, recursive=1)), make_params(80, 60))]
+    gpu = GpuEngine(scene, runs[0][0])
+    base = []
+    for f, rp in runs:
+        img = gpu.render(cam, f, rp)
+        assert gpu.stats.box_tests == 0 and gpu.stats.tri_tests == 0
+        base.append((img, gpu.stats.rays))
+    monkeypatch.setenv("RTX_COUNT_TESTS", "1")
+    for (f, rp), (want, want_rays) in zip(runs, base):
+        got = gpu.render(cam, f, rp)
+        assert gpu.stats.rays == want_rays and gpu.stats.box_tests > 0 and gpu.stats.tri_tests > 0
+        assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want)) and np.array_equal(np.isnan(got), np.isnan(want))
+    gpu.close()
