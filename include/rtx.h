@@ -281,11 +281,15 @@ int rtx_shade_device(const rtx_scene* scene, const rtx_ray* d_rays, size_t n, co
 /* Number of tiles each rank's compact buffer holds (the maximum over ranks). */
 int rtx_tiles_per_rank(const rtx_render_params* params);
 
-/* Queue this thread's GPU work on the caller's HIP stream (a hipStream_t, e.g.
+/* Queue this GPU's work on the caller's HIP stream (a hipStream_t, e.g.
  * the framework stream the device buffers are produced and consumed on) instead
  * of the library's own; NULL switches back.  With a stats pointer of NULL the
  * *_device entry points only enqueue and return, so frames can be pipelined
- * with the caller's other work on that stream. */
+ * with the caller's other work on that stream.  The setting is per GPU, not per
+ * thread: it applies to every thread that has called rtx_init for the same device.  Work still
+ * queued on the previous stream is ordered before whatever is queued on the new one (an event
+ * on the old stream that the new one waits for), because all calls share the GPU's work
+ * counters and scheduling buffers. */
 int rtx_set_stream(void* hip_stream);
 
 /* Page-locked host memory for buffers that travel to or from the GPU (a framebuffer handed to

@@ -1503,6 +1503,7 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;      // stream work is queued on (own or caller's)
     hipStream_t ownStream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evSwitch = nullptr;            // orders the old stream's work before the new stream's (rtx_set_stream)
     uint32_t* tickets = nullptr;              // device: kQueues work counters, kQueueStride words apart
     unsigned long long* stats = nullptr;      // device: kStatSlots copies of the S_COUNT words, kStatStride apart
     int numCUs = 0;
@@ -1683,6 +1684,8 @@ int checkCtx(const rtx_scene* scene)
         setErr("scene lives on device %d, this thread uses device %d", scene->device, g_ctx->device);
         return RTX_ERR_INVALID;
     }
+    // the host framework may have made another GPU current on this thread since rtx_init
+    HIP_TRY(hipSetDevice(g_ctx->device));
     return RTX_OK;
 }
 
@@ -2296,6 +2299,7 @@ int rtx_init(int device)
         c->stream = c->ownStream;
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev1));
+        HIP_TRY(hipEventCreate(&c->evSwitch));
         HIP_TRY(hipMalloc((void**)&c->tickets, kTicketBytes + kStatBytes)); // one allocation: cleared together
         c->stats = reinterpret_cast<unsigned long long*>(c->tickets + kTicketBytes / sizeof(uint32_t));
         HIP_TRY(hipMalloc((void**)&c->jump, kJumpCap * sizeof(uint32_t)));
@@ -2737,8 +2741,17 @@ int rtx_set_stream(void* hipStream)
 {
     if (int rc = checkCtx(nullptr))
         return rc;
-    std::lock_guard<std::mutex> launchLock(g_ctx->launch);
-    g_ctx->stream = hipStream ? static_cast<hipStream_t>(hipStream) : g_ctx->ownStream;
+    DeviceCtx* c = g_ctx;
+    std::lock_guard<std::mutex> launchLock(c->launch);
+    const hipStream_t next = hipStream ? static_cast<hipStream_t>(hipStream) : c->ownStream;
+    if (next != c->stream) {
+        // The work counters, the block order and the other per-device buffers are shared by
+        // every call on this GPU: what is still queued on the old stream must have finished
+        // with them before anything queued on the new stream touches them.
+        HIP_TRY(hipEventRecord(c->evSwitch, c->stream));
+        HIP_TRY(hipStreamWaitEvent(next, c->evSwitch, 0));
+        c->stream = next;
+    }
     return RTX_OK;
 }
 
