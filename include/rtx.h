@@ -258,6 +258,19 @@ int rtx_render(const rtx_scene* scene, const rtx_camera* camera, const rtx_featu
 /* Same with the framebuffer in HBM (device pointer); no host copy is made. */
 int rtx_render_device(const rtx_scene* scene, const rtx_camera* camera, const rtx_features* features,
                       const rtx_render_params* params, float* d_out_rgb, rtx_stats* stats);
+/* rtx_render_device for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Everything the kernels need beyond the scene, the parameters and the
+ * framebuffer (work-queue counters, statistics, the sampler's skip-ahead tables, the per-block
+ * costs and order of the frame scheduler) lives in one fixed array of about 3 MB per GPU inside
+ * the library, so the call makes no hipMalloc / hipFree and no host allocation either.
+ * Limits: width and height <= 4096 and at most 262 144 blocks of 8x8 pixels (tiles padded to
+ * tile_size); beyond them RTX_ERR_LIMIT.  Every call on a GPU shares that GPU's array, which
+ * keeps the previous call's block measurements: calls are serialised inside the library and
+ * ordered on the current stream (rtx_set_stream); frames issued on different streams at
+ * once would race.  Same frames, bit for bit, as rtx_render_device. */
+int rtx_render_device_static(const rtx_scene* scene, const rtx_camera* camera, const rtx_features* features,
+                             const rtx_render_params* params, float* d_out_rgb, rtx_stats* stats);
 /* Same, but this rank's tiles are written compactly: tile k of this rank
  * (k-th tile with index % tile_world == tile_rank, row-major tile order) occupies
  * floats [k*tile_size*tile_size*3, ...) of d_tiles, rows top-down inside the

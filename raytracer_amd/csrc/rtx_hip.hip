@@ -1498,34 +1498,65 @@ void setErr(const char* fmt, ...)
         }                                                                             \
     } while (0)
 
+// The device memory the kernels work in beyond a call's inputs and outputs: the work
+// queue's counters, the statistics, the skip-ahead tables of the driver-level RNG, and the
+// per-block costs / order / classes of the frame scheduler.  Shared by every call that
+// uses it (calls are serialised per GPU by DeviceCtx::launch and ordered on one stream).
+struct Arena {
+    uint32_t* tickets = nullptr;              // kQueues work counters, kQueueStride words apart
+    unsigned long long* stats = nullptr;      // kStatSlots copies of the S_COUNT words, kStatStride apart (follows the tickets)
+    uint32_t* queueBounds = nullptr;          // the work queue's plan, written by scanBlocksKernel
+    // skip-ahead tables of the driver-level RNG (jumpX | jumpY | jumpS), rebuilt when the frame shape changes
+    uint32_t* jump = nullptr;
+    int jumpMaxDim = 0, jumpMaxSamples = 0;   // capacity: entries of jumpX and jumpY each, entries of jumpS
+    int jumpW = -1, jumpH = -1, jumpS = -1, jumpD = -1;
+    // longest unit per 8x8 block on the previous frame and the visiting order derived from
+    // it; valid for the frame shape / partition recorded here
+    uint32_t *blockCost = nullptr, *blockOrder = nullptr; // maxBlocks (+ 64) words each
+    uint8_t* blockClass = nullptr;                         // maxBlocks bytes
+    uint32_t* classTable = nullptr;                        // kCostClasses x (maxBlocks / 64) words
+    uint32_t maxBlocks = 0;
+    int costW = -1, costH = -1, costTile = -1, costRank = -1, costWorld = -1, costDriver = -1;
+};
+constexpr size_t kTicketBytes = size_t(kQueues) * kQueueStride * sizeof(uint32_t), kStatBytes = size_t(kStatSlots) * kStatStride * sizeof(unsigned long long);
+constexpr int kJumpMaxDim = 32768, kJumpMaxSamples = 4096;
+
+// The arena of rtx_render_device_static: one file-scope array per GPU instead of
+// allocations, for callers that must not allocate.  Frames up to kFixedMaxDim pixels a
+// side and kFixedMaxBlocks 8x8 blocks (tile padding included).
+constexpr int kFixedMaxDim = 4096, kFixedMaxSamples = 1024;
+constexpr uint32_t kFixedMaxBlocks = 4096u * 4096u / 64u;
+constexpr size_t kFixedJumpWords = 2 * size_t(kFixedMaxDim) + kFixedMaxSamples;
+constexpr size_t alignUp256(size_t n) { return (n + 255) & ~size_t(255); }
+constexpr size_t kFixedTickets = 0;
+constexpr size_t kFixedBounds = kFixedTickets + alignUp256(kTicketBytes + kStatBytes);
+constexpr size_t kFixedJump = kFixedBounds + 256;
+constexpr size_t kFixedCost = kFixedJump + alignUp256((2 * size_t(kFixedMaxDim) + kFixedMaxSamples) * sizeof(uint32_t));
+constexpr size_t kFixedOrder = kFixedCost + alignUp256((size_t(kFixedMaxBlocks) + 64) * sizeof(uint32_t));
+constexpr size_t kFixedClass = kFixedOrder + alignUp256(size_t(kFixedMaxBlocks) * sizeof(uint32_t));
+constexpr size_t kFixedTable = kFixedClass + alignUp256(size_t(kFixedMaxBlocks) + 4);
+constexpr size_t kFixedBytes = kFixedTable + alignUp256(size_t(kCostClasses) * (kFixedMaxBlocks / 64) * sizeof(uint32_t));
+// In host code this name is only a handle for hipGetSymbolAddress: the array's device
+// address is looked up once per GPU in rtx_init and kept in DeviceCtx::fixedBase.
+static __device__ __align__(256) unsigned char scratch[kFixedBytes];
+
 struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;      // stream work is queued on (own or caller's)
     hipStream_t ownStream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evSwitch = nullptr;            // orders the old stream's work before the new stream's (rtx_set_stream)
-    uint32_t* tickets = nullptr;              // device: kQueues work counters, kQueueStride words apart
-    unsigned long long* stats = nullptr;      // device: kStatSlots copies of the S_COUNT words, kStatStride apart
     int numCUs = 0;
     std::mutex launch;                        // one frame / batch at a time per GPU
-    // skip-ahead tables of the driver-level RNG, rebuilt when the frame shape changes
-    uint32_t* jump = nullptr;                 // device: kJumpCap words
-    int jumpW = -1, jumpH = -1, jumpS = -1, jumpD = -1;
-    // per-tile cost of the previous frame and the visiting order derived from it;
-    // valid for the frame shape / partition recorded here
-    uint32_t *blockCost = nullptr, *blockOrder = nullptr; // device: kMaxOrderedBlocks words each
-    uint8_t* blockClass = nullptr;                         // device: kMaxOrderedBlocks bytes
-    uint32_t* classTable = nullptr;                        // device: kCostClasses x (kMaxOrderedBlocks / 64) words
-    uint32_t* queueBounds = nullptr;                      // device: the work queue's plan, written by scanBlocksKernel
-    int costW = -1, costH = -1, costTile = -1, costRank = -1, costWorld = -1, costDriver = -1;
+    Arena heap;                               // allocated in rtx_init
+    Arena fixed;                              // views into this GPU's copy of `scratch`
+    unsigned char* fixedBase = nullptr;       // device address of `scratch` on this GPU
     // device framebuffer behind the host-buffer entry point (rtx_render), kept from call to
     // call and grown when a larger frame comes; hostFrame serialises its users
     std::mutex hostFrame;
     float* frame = nullptr;
     size_t frameBytes = 0;
 };
-constexpr size_t kTicketBytes = size_t(kQueues) * kQueueStride * sizeof(uint32_t), kStatBytes = size_t(kStatSlots) * kStatStride * sizeof(unsigned long long);
-constexpr int kJumpMaxDim = 32768, kJumpMaxSamples = 4096, kJumpCap = 2 * kJumpMaxDim + kJumpMaxSamples;
 
 uint64_t hostMulMod(uint64_t a, uint64_t b) { return (a * b) % 2147483647ull; }
 uint64_t hostPowMod(uint64_t base, uint64_t e)
@@ -1608,10 +1639,10 @@ int gridFor(const DeviceCtx* c, const void* kernel)
 }
 // Units per claim: small, so that the last chunks of a frame are short, but with
 // enough units that a wave's claim for the next chunk returns before it is needed.
-WorkQueue makeQueue(const DeviceCtx* c, uint32_t nUnits)
+WorkQueue makeQueue(const DeviceCtx* c, const Arena* a, uint32_t nUnits)
 {
     WorkQueue q;
-    q.tickets = c->tickets;
+    q.tickets = a->tickets;
     q.nUnits = nUnits;
     const uint32_t waves = uint32_t(c->numCUs) * 16u;
     q.chunk = std::min(8u, std::max(1u, nUnits / (waves * 32u)));
@@ -1704,7 +1735,7 @@ bool wantCounters()
 
 // With stats == NULL the call only queues work and returns; with stats it waits
 // for the kernel and reads the counters back.
-int fetchStats(DeviceCtx* c, rtx_stats* stats, double t0)
+int fetchStats(DeviceCtx* c, const Arena* a, rtx_stats* stats, double t0)
 {
     if (!stats)
         return RTX_OK;
@@ -1712,8 +1743,8 @@ int fetchStats(DeviceCtx* c, rtx_stats* stats, double t0)
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     {
-        std::vector<unsigned long long> slots(size_t(kStatSlots) * kStatStride);
-        HIP_TRY(hipMemcpy(slots.data(), c->stats, kStatBytes, hipMemcpyDeviceToHost));
+        unsigned long long slots[size_t(kStatSlots) * kStatStride]; // (on the stack: this path must not allocate)
+        HIP_TRY(hipMemcpy(slots, a->stats, kStatBytes, hipMemcpyDeviceToHost));
         unsigned long long h[S_COUNT] = {};
         for (int i = 0; i < kStatSlots; i++)
             for (int j = 0; j < S_COUNT; j++)
@@ -1749,10 +1780,11 @@ int traceImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* d
     A.rays = dRays;
     A.hits = dHits;
     A.n = n;
+    const Arena* a = &c->heap;
     A.work.nUnits = uint32_t((n + 63) / 64);
-    A.work = makeQueue(c, A.work.nUnits);
-    A.stats = c->stats;
-    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
+    A.work = makeQueue(c, a, A.work.nUnits);
+    A.stats = a->stats;
+    HIP_TRY(hipMemsetAsync(a->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
     if (stats)
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
@@ -1767,7 +1799,7 @@ int traceImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* d
     }
     if (stats)
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    return fetchStats(c, stats, t0);
+    return fetchStats(c, a, stats, t0);
 }
 
 struct TileGeom {
@@ -1926,9 +1958,10 @@ bool cullRectangle(const float* boxLo, const float* boxHi, const rtx_camera* cam
     return true;
 }
 
-int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dOut, bool compact, rtx_stats* stats, double t0)
+int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dOut, bool compact, rtx_stats* stats, double t0, bool fixedArena = false)
 {
     DeviceCtx* c = g_ctx;
+    Arena* a = fixedArena ? &c->fixed : &c->heap;
     std::lock_guard<std::mutex> launchLock(c->launch);
     TileGeom g;
     if (int rc = tileGeom(p, g))
@@ -1937,6 +1970,14 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     if (driver < RTX_DRIVER_PLAIN || driver > RTX_DRIVER_MOTION_BLUR) {
         setErr("unknown driver %d", driver);
         return RTX_ERR_INVALID;
+    }
+    if (fixedArena) {
+        const uint64_t blocks = uint64_t(g.tilesMine) * uint64_t(g.ts / 8) * uint64_t(g.ts / 8);
+        if (p->width > kFixedMaxDim || p->height > kFixedMaxDim || blocks > kFixedMaxBlocks) {
+            setErr("rtx_render_device_static: frame %dx%d (%llu blocks of 8x8 pixels with tile padding) exceeds the fixed workspace (%dx%d pixels, %u blocks)", p->width,
+                p->height, (unsigned long long)blocks, kFixedMaxDim, kFixedMaxDim, kFixedMaxBlocks);
+            return RTX_ERR_LIMIT;
+        }
     }
     const int stack = pickStack(scene->numLevels);
     if (stack < 0) {
@@ -2010,8 +2051,8 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         return RTX_ERR_LIMIT;
     }
     A.work.nUnits = uint32_t(units);
-    A.work = makeQueue(c, A.work.nUnits);
-    A.stats = c->stats;
+    A.work = makeQueue(c, a, A.work.nUnits);
+    A.stats = a->stats;
 
     // the full kernel carries the reflection / transparency / area-light /
     // texture / environment machinery; the lean one is enough otherwise
@@ -2113,16 +2154,19 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     }
 
     // skip-ahead tables for the drivers that draw from the sequential engine
-    A.jumpX = c->jump;
-    A.jumpY = c->jump + kJumpMaxDim;
-    A.jumpS = c->jump + 2 * kJumpMaxDim;
+    A.jumpX = a->jump;
+    A.jumpY = a->jump + a->jumpMaxDim;
+    A.jumpS = a->jump + 2 * a->jumpMaxDim;
     A.jumpSamples = 0;
     if (sampled) {
         const int d = driver == RTX_DRIVER_MRAYS ? 2 : driver == RTX_DRIVER_DOF ? 3 : 1;
-        const int ns = std::min(A.samples, kJumpMaxSamples);
+        const int ns = std::min(A.samples, a->jumpMaxSamples);
         A.jumpSamples = ns;
-        if (c->jumpW != A.W || c->jumpH != A.H || c->jumpS != A.samples || c->jumpD != d) {
-            std::vector<uint32_t> t(size_t(A.W) + size_t(A.H) + size_t(ns));
+        if (a->jumpW != A.W || a->jumpH != A.H || a->jumpS != A.samples || a->jumpD != d) {
+            // (the fixed arena's path must not allocate: its tables fit the stack)
+            uint32_t onStack[kFixedJumpWords];
+            std::vector<uint32_t> onHeap(fixedArena ? 0 : size_t(A.W) + size_t(A.H) + size_t(ns));
+            uint32_t* const t = fixedArena ? onStack : onHeap.data();
             const uint64_t perPixel = uint64_t(d) * uint64_t(A.samples);
             const uint64_t g = hostPowMod(16807, perPixel), gRow = hostPowMod(g, uint64_t(A.W)), gS = hostPowMod(16807, uint64_t(d));
             uint64_t v = 1;
@@ -2134,11 +2178,11 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
             v = 1;
             for (int i = 0; i < ns; i++, v = hostMulMod(v, gS))
                 t[size_t(A.W) + size_t(A.H) + size_t(i)] = uint32_t(v);
-            HIP_TRY(hipMemcpyAsync(c->jump, t.data(), size_t(A.W) * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->jump + kJumpMaxDim, t.data() + A.W, size_t(A.H) * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->jump + 2 * kJumpMaxDim, t.data() + A.W + A.H, size_t(ns) * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(a->jump, t, size_t(A.W) * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(a->jump + a->jumpMaxDim, t + A.W, size_t(A.H) * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(a->jump + 2 * a->jumpMaxDim, t + A.W + A.H, size_t(ns) * 4, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream)); // t goes out of scope
-            c->jumpW = A.W, c->jumpH = A.H, c->jumpS = A.samples, c->jumpD = d;
+            a->jumpW = A.W, a->jumpH = A.H, a->jumpS = A.samples, a->jumpD = d;
         }
     }
     // Longest blocks first: some units (grazing shadow rays, silhouettes) run fifty times
@@ -2152,33 +2196,33 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.blocksMine = uint32_t(g.tilesMine) * A.blocksPerTile;
     A.costStride = (A.blocksMine + 63u) / 64u;
     A.costFloor = 0;
-    if (A.unitsPerBlockLog2 >= 0 && A.blocksMine > 1 && A.blocksMine <= uint32_t(kMaxOrderedBlocks) && !getenv("RTX_NO_BLOCK_ORDER")) {
-        A.blockCost = c->blockCost;
-        const bool measured = !(c->costW != A.W || c->costH != A.H || c->costTile != g.ts || c->costRank != g.rank || c->costWorld != g.world || c->costDriver != driver);
+    if (A.unitsPerBlockLog2 >= 0 && A.blocksMine > 1 && A.blocksMine <= a->maxBlocks && !getenv("RTX_NO_BLOCK_ORDER")) {
+        A.blockCost = a->blockCost;
+        const bool measured = !(a->costW != A.W || a->costH != A.H || a->costTile != g.ts || a->costRank != g.rank || a->costWorld != g.world || a->costDriver != driver);
         if (!measured) {
             // Nothing measured yet for frames of this shape.  Where blocks can be told
             // unable to see the scene the frame is ordered all the same (every other block
             // counts as never measured, i.e. expensive, and keeps its place in the list),
             // so that those blocks stay out of the queue; otherwise it runs in list order.
-            HIP_TRY(hipMemsetAsync(c->blockCost, 0, size_t(A.costStride) * 64 * sizeof(uint32_t), c->stream));
-            c->costW = A.W, c->costH = A.H, c->costTile = g.ts, c->costRank = g.rank, c->costWorld = g.world, c->costDriver = driver;
+            HIP_TRY(hipMemsetAsync(a->blockCost, 0, size_t(A.costStride) * 64 * sizeof(uint32_t), c->stream));
+            a->costW = A.W, a->costH = A.H, a->costTile = g.ts, a->costRank = g.rank, a->costWorld = g.world, a->costDriver = driver;
         }
         ordered = measured || A.cullOn;
         if (ordered) {
             auto envClass = [](const char* name, uint32_t fallback) { const char* e = getenv(name); return e ? uint32_t(atoi(e)) : fallback; };
             const uint32_t nSteps = (A.blocksMine + 63u) / 64u, groups = (A.blocksMine + 255u) / 256u;
-            hipLaunchKernelGGL(classifyBlocksKernel, dim3(groups), dim3(256), 0, c->stream, A, c->blockClass, c->classTable, nSteps, c->tickets, uint32_t((kTicketBytes + kStatBytes) / sizeof(uint32_t)));
-            hipLaunchKernelGGL(scanBlocksKernel, dim3(1), dim3(kScanThreads), 0, c->stream, c->classTable, nSteps, A.unitsPerBlockLog2, c->queueBounds, uint32_t(c->numCUs) * 16u,
+            hipLaunchKernelGGL(classifyBlocksKernel, dim3(groups), dim3(256), 0, c->stream, A, a->blockClass, a->classTable, nSteps, a->tickets, uint32_t((kTicketBytes + kStatBytes) / sizeof(uint32_t)));
+            hipLaunchKernelGGL(scanBlocksKernel, dim3(1), dim3(kScanThreads), 0, c->stream, a->classTable, nSteps, A.unitsPerBlockLog2, a->queueBounds, uint32_t(c->numCUs) * 16u,
                 envClass("RTX_SINGLE_CLASS", kLastSingleClass), envClass("RTX_HEAVY_CLASS", kLastHeavyClass));
-            hipLaunchKernelGGL(placeBlocksKernel, dim3(groups), dim3(256), 0, c->stream, c->blockClass, A.blocksMine, c->classTable, nSteps, c->blockOrder);
-            A.blockOrder = c->blockOrder;
+            hipLaunchKernelGGL(placeBlocksKernel, dim3(groups), dim3(256), 0, c->stream, a->blockClass, A.blocksMine, a->classTable, nSteps, a->blockOrder);
+            A.blockOrder = a->blockOrder;
             A.costFloor = kCostFloorTicks;
-            A.work.plan = c->queueBounds;
+            A.work.plan = a->queueBounds;
             A.work.nChunks = A.work.nUnits; // (for the grid size: at most)
         }
     }
     if (!ordered)
-        HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
+        HIP_TRY(hipMemsetAsync(a->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
     if (stats) // (an event record costs the stream a few microseconds around the kernel: only when the time is asked for)
         HIP_TRY(hipEventRecord(c->ev0, c->stream)); // kernel_ms is the render kernel's time
     if (A.work.nUnits) {
@@ -2193,7 +2237,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     }
     if (stats)
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    return fetchStats(c, stats, t0);
+    return fetchStats(c, a, stats, t0);
 }
 
 template <int STACK>
@@ -2246,13 +2290,14 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
         return rc;
     A.glossyRays = p->glossy_rays > 0 ? p->glossy_rays : 5;
     A.seed = p->seed;
+    const Arena* a = &c->heap;
     A.work.nUnits = uint32_t((n + 63) / 64);
-    A.work = makeQueue(c, A.work.nUnits);
-    A.stats = c->stats;
+    A.work = makeQueue(c, a, A.work.nUnits);
+    A.stats = a->stats;
     S.rays = dRays;
     S.out = dOut;
     S.n = n;
-    HIP_TRY(hipMemsetAsync(c->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
+    HIP_TRY(hipMemsetAsync(a->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
     if (stats)
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
@@ -2267,7 +2312,7 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
     }
     if (stats)
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    return fetchStats(c, stats, t0);
+    return fetchStats(c, a, stats, t0);
 }
 
 } // namespace
@@ -2292,22 +2337,64 @@ int rtx_init(int device)
     std::lock_guard<std::mutex> lock(g_ctxMutex);
     DeviceCtx* c = &g_ctxs[device];
     if (c->device < 0) {
+        // everything is made in locals and committed at the end, so that a failure
+        // halfway leaves nothing behind and a later call starts from scratch
+        hipStream_t stream = nullptr;
+        hipEvent_t events[3] = {};
+        void* mem[6] = {};
+        const size_t bytes[6] = { kTicketBytes + kStatBytes, // one allocation: cleared together
+            (2 * size_t(kJumpMaxDim) + kJumpMaxSamples) * sizeof(uint32_t), (size_t(kMaxOrderedBlocks) + 64) * sizeof(uint32_t),
+            size_t(kMaxOrderedBlocks) * sizeof(uint32_t), size_t(kMaxOrderedBlocks) + 4, size_t(kCostClasses) * (kMaxOrderedBlocks / 64) * sizeof(uint32_t) + 256 };
         hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        unsigned char* fixedBase = nullptr;
+        hipError_t e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess)
+            e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        for (int i = 0; i < 3 && e == hipSuccess; i++)
+            e = hipEventCreate(&events[i]);
+        for (int i = 0; i < 6 && e == hipSuccess; i++)
+            e = hipMalloc(&mem[i], bytes[i]);
+        // this GPU's copy of the file-scope array (each device holds its own, at its own address)
+        if (e == hipSuccess)
+            e = hipGetSymbolAddress(reinterpret_cast<void**>(&fixedBase), HIP_SYMBOL(scratch));
+        if (e != hipSuccess) {
+            setErr("rtx_init(%d) failed: %s", device, hipGetErrorString(e));
+            for (void* m : mem)
+                if (m)
+                    (void)hipFree(m);
+            for (hipEvent_t ev : events)
+                if (ev)
+                    (void)hipEventDestroy(ev);
+            if (stream)
+                (void)hipStreamDestroy(stream);
+            return RTX_ERR_DEVICE;
+        }
         c->numCUs = prop.multiProcessorCount;
-        HIP_TRY(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
-        c->stream = c->ownStream;
-        HIP_TRY(hipEventCreate(&c->ev0));
-        HIP_TRY(hipEventCreate(&c->ev1));
-        HIP_TRY(hipEventCreate(&c->evSwitch));
-        HIP_TRY(hipMalloc((void**)&c->tickets, kTicketBytes + kStatBytes)); // one allocation: cleared together
-        c->stats = reinterpret_cast<unsigned long long*>(c->tickets + kTicketBytes / sizeof(uint32_t));
-        HIP_TRY(hipMalloc((void**)&c->jump, kJumpCap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->blockCost, (kMaxOrderedBlocks + 64) * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->blockOrder, kMaxOrderedBlocks * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->blockClass, kMaxOrderedBlocks + 4));
-        HIP_TRY(hipMalloc((void**)&c->classTable, size_t(kCostClasses) * (kMaxOrderedBlocks / 64) * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->queueBounds, 256));
+        c->ownStream = c->stream = stream;
+        c->ev0 = events[0], c->ev1 = events[1], c->evSwitch = events[2];
+        Arena& h = c->heap;
+        h.tickets = static_cast<uint32_t*>(mem[0]);
+        h.stats = reinterpret_cast<unsigned long long*>(h.tickets + kTicketBytes / sizeof(uint32_t));
+        h.jump = static_cast<uint32_t*>(mem[1]);
+        h.jumpMaxDim = kJumpMaxDim, h.jumpMaxSamples = kJumpMaxSamples;
+        h.blockCost = static_cast<uint32_t*>(mem[2]);
+        h.blockOrder = static_cast<uint32_t*>(mem[3]);
+        h.blockClass = static_cast<uint8_t*>(mem[4]);
+        h.classTable = static_cast<uint32_t*>(mem[5]);
+        h.queueBounds = h.classTable + size_t(kCostClasses) * (kMaxOrderedBlocks / 64);
+        h.maxBlocks = uint32_t(kMaxOrderedBlocks);
+        c->fixedBase = fixedBase;
+        Arena& x = c->fixed;
+        x.tickets = reinterpret_cast<uint32_t*>(fixedBase + kFixedTickets);
+        x.stats = reinterpret_cast<unsigned long long*>(x.tickets + kTicketBytes / sizeof(uint32_t));
+        x.queueBounds = reinterpret_cast<uint32_t*>(fixedBase + kFixedBounds);
+        x.jump = reinterpret_cast<uint32_t*>(fixedBase + kFixedJump);
+        x.jumpMaxDim = kFixedMaxDim, x.jumpMaxSamples = kFixedMaxSamples;
+        x.blockCost = reinterpret_cast<uint32_t*>(fixedBase + kFixedCost);
+        x.blockOrder = reinterpret_cast<uint32_t*>(fixedBase + kFixedOrder);
+        x.blockClass = fixedBase + kFixedClass;
+        x.classTable = reinterpret_cast<uint32_t*>(fixedBase + kFixedTable);
+        x.maxBlocks = kFixedMaxBlocks;
         c->device = device;
     }
     g_ctx = c;
@@ -2604,6 +2691,18 @@ int rtx_render_device(const rtx_scene* scene, const rtx_camera* cam, const rtx_f
         return RTX_ERR_INVALID;
     }
     return renderImpl(scene, cam, f, p, dOut, false, stats, t0);
+}
+
+int rtx_render_device_static(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dOut, rtx_stats* stats)
+{
+    const double t0 = nowMs();
+    if (int rc = checkCtx(scene))
+        return rc;
+    if (!scene || !cam || !f || !p || !dOut) {
+        setErr("rtx_render_device_static: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    return renderImpl(scene, cam, f, p, dOut, false, stats, t0, true);
 }
 
 int rtx_render_tiles_device(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dTiles, rtx_stats* stats)
