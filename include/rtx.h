@@ -191,7 +191,8 @@ typedef enum rtx_driver {
     RTX_DRIVER_PLAIN = 0,         /* renderRayTracing               src/render.cpp:69-90   */
     RTX_DRIVER_MRAYS = 1,         /* renderRayTracingMRaysPerPixel  src/render.cpp:152-183 */
     RTX_DRIVER_DOF = 2,           /* renderRayTracingDepthOfField   src/render.cpp:92-126  */
-    RTX_DRIVER_TRANSPARENCY = 3,  /* renderRayTracingTransparency   src/render.cpp:129-150 */
+    RTX_DRIVER_TRANSPARENCY = 3,  /* renderRayTracingTransparency   src/render.cpp:129-150; at most 16
+                                     translucent layers per camera ray (see rtx_stats.layer_overflows) */
     RTX_DRIVER_MOTION_BLUR = 4    /* renderRayTracingMotionBlur     src/render.cpp:190-253 (second and later calls) */
 } rtx_driver;
 
@@ -222,6 +223,13 @@ typedef struct rtx_stats {
     uint64_t shaded_hits;
     double   kernel_ms;       /* device time of the render / trace kernel (HIP events) */
     double   total_ms;        /* wall time of the call                          */
+    uint64_t rays_traced;     /* of the rays counted above, those that walked the scene on the
+                                 device: camera rays of 8x8 blocks that cannot see the scene's
+                                 bounds are counted (the reference makes and tests them) but never
+                                 made, and a light sample behind the surface needs no ray */
+    uint64_t layer_overflows; /* RTX_DRIVER_TRANSPARENCY: camera rays that met more than 16
+                                 translucent surfaces; the 17th was taken as opaque, so their pixels
+                                 differ from the reference's unbounded recursion */
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;   /* device-resident scene, reference-counted */

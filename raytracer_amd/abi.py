@@ -42,7 +42,8 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64),
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("shaded_hits", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("rays_traced", C.c_uint64), ("layer_overflows", C.c_uint64)]
 
     @property
     def rays(self):

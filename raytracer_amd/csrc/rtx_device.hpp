@@ -511,11 +511,16 @@ RTX_DEV bool closestHit(const DScene& sc, LaneStack<STACK>& st, const rtx_featur
 //    is every hit before it, so the walk may stop there.
 // The margins (2x and 4x) dwarf fp32 rounding for coordinates up to 64; beyond
 // that the query runs unshortened.
+// (the facing test: false for a light sample behind the viewer-side surface)
+RTX_DEV bool lightFacesSurface(V3 pos, V3 hp, V3 visN)
+{
+    return !(dot(normalize(pos - hp), normalize(visN)) < -1e-6f);
+}
+// (the ray part; the caller has made the facing test)
 template <int STACK, bool COUNT>
 RTX_DEV float lightVisibility(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, V3 pos, V3 hp, V3 visN, TraceCounters& tc)
 {
-    if (dot(normalize(pos - hp), normalize(visN)) < -1e-6f)
-        return 0.0f;
+    (void)visN;
     const V3 sd = hp - pos;
     const float len = length(sd);
     const float scale = fmaxf(fmaxf(fmaxf(fabsf(hp.x), fabsf(hp.y)), fabsf(hp.z)), fmaxf(fmaxf(fabsf(pos.x), fabsf(pos.y)), fabsf(pos.z)));

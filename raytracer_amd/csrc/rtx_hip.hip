@@ -40,18 +40,22 @@ constexpr int kMaxDepth = 8;    // frames of the reflection recursion kept per l
 constexpr int kMaxLayers = 16;  // transparent layers along one camera ray
 
 // ------------------------------------------------------------ statistics ----
-enum { S_PRIMARY = 0, S_SHADOW, S_BOUNCE, S_BOX, S_TRI, S_SHADED, S_COUNT };
+enum { S_PRIMARY = 0, S_SHADOW, S_BOUNCE, S_BOX, S_TRI, S_SHADED, S_TRACED, S_OVERFLOW, S_COUNT };
 
 // Ray counters are kept per wave (a ballot's population count is the same in
 // every lane, so they live in scalar registers); the optional per-lane box /
 // triangle test counters are summed across the wave at the end.
 struct LaneCounters {
     uint32_t primary = 0, shadow = 0, bounce = 0, shaded = 0;
+    uint32_t traced = 0;   // counted rays that did walk the scene (not: rays of blocks that cannot see it, light samples behind the surface)
+    uint32_t overflow = 0; // camera samples whose transparency chain was cut at kMaxLayers
     TraceCounters tc { 0, 0 };
     RTX_DEV void countPrimary(bool lane) { primary += __popcll(__ballot(lane)); }
     RTX_DEV void countShadow(bool lane) { shadow += __popcll(__ballot(lane)); }
     RTX_DEV void countBounce(bool lane) { bounce += __popcll(__ballot(lane)); }
     RTX_DEV void countShaded(bool lane) { shaded += __popcll(__ballot(lane)); }
+    RTX_DEV void countTraced(bool lane) { traced += __popcll(__ballot(lane)); }
+    RTX_DEV void countOverflow(bool lane) { overflow += __popcll(__ballot(lane)); }
 };
 
 #ifdef RTX_PROBE
@@ -92,6 +96,9 @@ RTX_DEV void flushCounters(const LaneCounters& c, unsigned long long* stats)
         atomicAdd(&slot[S_SHADOW], (unsigned long long)c.shadow);
         atomicAdd(&slot[S_BOUNCE], (unsigned long long)c.bounce);
         atomicAdd(&slot[S_SHADED], (unsigned long long)c.shaded);
+        atomicAdd(&slot[S_TRACED], (unsigned long long)c.traced);
+        if (c.overflow)
+            atomicAdd(&slot[S_OVERFLOW], (unsigned long long)c.overflow);
         if (COUNT) {
             atomicAdd(&slot[S_BOX], (unsigned long long)bx);
             atomicAdd(&slot[S_TRI], (unsigned long long)tr);
@@ -223,6 +230,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceArgs A)
         for (uint32_t unit = first; unit < last; unit++) {
         const uint64_t i = uint64_t(unit) * 64 + lane;
         lc.countPrimary(i < A.n);
+        lc.countTraced(i < A.n);
         if (i < A.n) {
             const rtx_ray r = A.rays[i];
             float t = r.t;
@@ -531,6 +539,7 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     V3 envAvg = mk(0, 0, 0);
 
     bool shadedPending = false; // counted at the loop head, where the wave is converged
+    bool overflowPending = false;
     bool firstQuery = true;
     while (__any(state != PS_DONE)) {
         const uint64_t pending = FULL ? __ballot(state == PS_AREA) : 0ull;
@@ -539,6 +548,10 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
         const bool coopFan = pendingFan != 0;
         lc.countShaded(shadedPending);
         shadedPending = false;
+        if (FULL) {
+            lc.countOverflow(overflowPending);
+            overflowPending = false;
+        }
 
         // ---- the ray this lane traces in this iteration
         V3 qo = ro, qd = rd;
@@ -651,6 +664,7 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
         int bestK = -1, sphere = -1;
         V3 sphereN = mk(0, 0, 0);
         {
+            lc.countTraced(trace);
             if (trace)
                 any = closestHit<STACK, COUNT, true>(sc, st, f, qo, qd, t, bestK, sphere, sphereN, lc.tc, qStop, qLimit);
             if (FAN && !coop && !coopFan && state == PS_RADIANCE && preTraced) {
@@ -749,6 +763,7 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
             if (transparencyDriver && level == 0) {
                 const float alpha = (any && hit.material >= 0) ? sc.mats[hit.material].transparency : 1.0f;
                 lastLayer = !any || alpha == 1.0f || nLayers >= kMaxLayers;
+                overflowPending = any && alpha != 1.0f && nLayers >= kMaxLayers; // (the chain is cut here: reported in rtx_stats)
                 if (!lastLayer) {
                     layerAlpha[nLayers] = alpha;
                     const float adv = float(double(t) + 1e-6);
@@ -987,6 +1002,8 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
         }
     }
     lc.countShaded(shadedPending);
+    if (FULL)
+        lc.countOverflow(overflowPending);
     return result;
 }
 
@@ -1005,6 +1022,7 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
     Hit hit;
     bool any = false;
     lc.countPrimary(active);
+    lc.countTraced(active);
     if (active)
         any = intersectScene<STACK, COUNT>(sc, st, f, o, d, t, hit, lc.tc);
     const bool shade = any && f.enable_shading;
@@ -1035,8 +1053,10 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
         if (f.enable_hard_shadow) {
             // src/light.cpp:70-102
             lc.countShadow(shade);
+            const bool facing = shade && lightFacesSurface(pos, hp, visN);
+            lc.countTraced(facing);
             if (shade)
-                sh = sh * lightVisibility<STACK, COUNT>(sc, st, f, pos, hp, visN, lc.tc);
+                sh = sh * (facing ? lightVisibility<STACK, COUNT>(sc, st, f, pos, hp, visN, lc.tc) : 0.0f);
         }
         if (shade)
             result = result + sh;
@@ -1755,6 +1775,8 @@ int fetchStats(DeviceCtx* c, const Arena* a, rtx_stats* stats, double t0)
         stats->box_tests = h[S_BOX];
         stats->tri_tests = h[S_TRI];
         stats->shaded_hits = h[S_SHADED];
+        stats->rays_traced = h[S_TRACED];
+        stats->layer_overflows = h[S_OVERFLOW];
         stats->kernel_ms = ms;
         stats->total_ms = nowMs() - t0;
     }
@@ -2419,7 +2441,17 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
         setErr("rtx_scene_create: scene too large");
         return nullptr;
     }
+    {
+        const struct { const void* p; uint64_t n; const char* what; } arrays[] = { { d->nodes, d->n_nodes, "nodes" }, { d->materials, d->n_materials, "materials" },
+            { d->textures, d->n_textures, "textures" }, { d->texels, d->n_texels, "texels" }, { d->lights, d->n_lights, "lights" }, { d->spheres, d->n_spheres, "spheres" } };
+        for (const auto& a : arrays)
+            if (a.n && !a.p) {
+                setErr("rtx_scene_create: %llu %s but a NULL array", (unsigned long long)a.n, a.what);
+                return nullptr;
+            }
+    }
     const bool emptyTree = d->root_ref == INT32_MIN;
+    int walkedLevels = 0; // inner nodes on the longest path from the root, plus the leaf
     if (!emptyTree) {
         auto refOk = [&](int32_t r) { return r >= 0 ? uint32_t(r) < d->n_nodes : uint32_t(~r) < d->n_tris; };
         if (!refOk(d->root_ref)) {
@@ -2435,6 +2467,27 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
         if (d->n_tris && !(d->tris[d->n_tris - 1].flags & RTX_TRI_LAST_IN_LEAF)) {
             setErr("rtx_scene_create: last triangle record lacks the end-of-leaf flag");
             return nullptr;
+        }
+        // The nodes reachable from the root must form a tree: the traversal's stack is sized by
+        // its depth, and a node reached twice (a cycle, or a shared subtree that could hide one)
+        // would let a walk run on forever or past its stack.
+        std::vector<uint8_t> seen(d->n_nodes, 0);
+        std::vector<std::pair<int32_t, int>> todo; // (inner node, its depth)
+        if (d->root_ref >= 0)
+            todo.push_back({ d->root_ref, 1 });
+        walkedLevels = 1;
+        while (!todo.empty()) {
+            const auto [node, depth] = todo.back();
+            todo.pop_back();
+            if (seen[size_t(node)]) {
+                setErr("rtx_scene_create: node %d is reachable twice (the nodes must form a tree)", node);
+                return nullptr;
+            }
+            seen[size_t(node)] = 1;
+            walkedLevels = std::max(walkedLevels, depth + 1);
+            for (const int32_t child : { d->nodes[node].ref0, d->nodes[node].ref1 })
+                if (child >= 0)
+                    todo.push_back({ child, depth + 1 });
         }
     }
     for (uint32_t i = 0; i < d->n_tris; i++) {
@@ -2489,7 +2542,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
         return nullptr;
     }
     s->device = g_ctx->device;
-    s->numLevels = d->num_levels;
+    s->numLevels = std::max(d->num_levels, walkedLevels); // (never less than the tree really has: it sizes the traversal stack)
     // A shallow cut through the tree, level by level while it stays within
     // kMaxCutBoxes: its boxes together hold every triangle.
     if (d->root_ref >= 0) {

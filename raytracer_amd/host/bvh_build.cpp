@@ -1,11 +1,13 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
 #include <map>
 #include <stdexcept>
+#include <string>
 #include <thread>
 #include <unordered_map>
 
@@ -60,6 +62,8 @@ struct Builder {
     static constexpr size_t kParallelAbove = 1u << 17; // triangles in a subtree worth a thread of its own
     static constexpr int kParallelDepth = 5;           // at most 2^5 ordering threads
 
+    std::atomic<bool> degenerate { false };
+
     bool isLeaf(size_t n, int depth) const { return (maxDepth > -1 && maxDepth <= depth) || n < 2; }
 
     void order(size_t* idx, size_t begin, size_t n, int direction, int depth, std::vector<Split>& splits)
@@ -89,6 +93,12 @@ struct Builder {
             // getMedian, src/bounding_volume_hierarchy.cpp:65-73
             std::nth_element(r, r + n / 2, r + n, cmp);
             split = n / 2;
+        }
+        if (split == 0 || split >= n) {
+            // (only NaN sweep costs can leave the split at the range's start; the recursion below
+            // would take an empty half for a leaf.  Reported by build(), on the calling thread.)
+            degenerate.store(true);
+            return;
         }
         splits.push_back(Split { uint64_t(begin) * 64u + uint64_t(depth), split });
         const int next = (direction + 1) % 3;
@@ -172,6 +182,8 @@ struct Builder {
     {
         std::vector<Split> splits;
         order(idx, 0, n, 0, 0, splits);
+        if (degenerate.load())
+            throw std::invalid_argument("BVH build: a node could not be split (non-finite triangle centroids)");
         std::unordered_map<uint64_t, size_t> splitOf;
         splitOf.reserve(splits.size() * 2);
         for (const Split& s : splits)
@@ -363,6 +375,9 @@ FlatScene flattenScene(const Scene& scene, const Features& features)
             if (t.x >= m.vertices.size() || t.y >= m.vertices.size() || t.z >= m.vertices.size())
                 throw std::out_of_range("triangle references a vertex outside its mesh");
             const vec3 p0 = m.vertices[t.x].position, p1 = m.vertices[t.y].position, p2 = m.vertices[t.z].position;
+            for (const vec3& q : { p0, p1, p2 })
+                if (!std::isfinite(q.x) || !std::isfinite(q.y) || !std::isfinite(q.z))
+                    throw std::invalid_argument("mesh " + std::to_string(mi) + ": triangle " + std::to_string(j) + " has a vertex position that is not finite");
             Prim p;
             p.mesh = int(mi);
             p.tri = int(j);

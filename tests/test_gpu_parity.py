@@ -343,7 +343,8 @@ def test_c_abi_rejects_bad_input(gpu_device):
 
     # inconsistent scene descriptions are refused at creation
     flat = engine.flatten(scene, f)
-    for breakage, word in (("ref", b"reference"), ("material", b"material"), ("flag", b"last"), ("light", b"light"), ("bins", b"bins")):
+    for breakage, word in (("ref", b"reference"), ("material", b"material"), ("flag", b"last"), ("light", b"light"), ("bins", b"bins"),
+                           ("cycle", b"twice"), ("shared", b"twice"), ("null materials", b"null"), ("null lights", b"null")):
         d = flat.desc()
         keep = []
         if breakage == "ref":
@@ -366,6 +367,24 @@ def test_c_abi_rejects_bad_input(gpu_device):
             arr[0, 0] = 5
             keep.append(arr)
             d.lights = arr.ctypes.data
+        elif breakage in ("cycle", "shared"):
+            arr = np.ctypeslib.as_array(C.cast(d.nodes, C.POINTER(C.c_int32)), shape=(d.n_nodes, 16)).copy()
+            inner = [i for i in range(d.n_nodes) if arr[i, 12] >= 0 or arr[i, 13] >= 0]
+            assert inner and d.root_ref >= 0
+            if breakage == "cycle":       # an inner node becomes its own grandchild: a walk would never end
+                i = inner[-1]
+                arr[i, 12 if arr[i, 12] >= 0 else 13] = d.root_ref
+            else:                          # both children of the root are the same subtree
+                arr[d.root_ref, 13] = arr[d.root_ref, 12] if arr[d.root_ref, 12] >= 0 else arr[d.root_ref, 13]
+                arr[d.root_ref, 12] = arr[d.root_ref, 13]
+                if arr[d.root_ref, 12] < 0:
+                    continue               # (a two-leaf tree has no subtree to share)
+            keep.append(arr)
+            d.nodes = arr.ctypes.data
+        elif breakage == "null materials":
+            d.materials = None
+        elif breakage == "null lights":
+            d.lights = None
         else:
             d.n_env_bins = 3
             d.env_bins = None
@@ -373,6 +392,47 @@ def test_c_abi_rejects_bad_input(gpu_device):
         assert not h, breakage
         assert word in hip.rtx_last_error().lower(), (breakage, hip.rtx_last_error())
     flat.close()
+    gpu.close()
+
+
+def _stacked_quads(layers, alpha=0.5):
+    """`layers` translucent quads one behind the other in front of an opaque one, facing a
+    camera on the -z axis."""
+    from raytracer_amd.scene import SceneData
+    s = SceneData()
+    quad = [[0, 1, 2], [0, 2, 3]]
+    for k in range(layers + 1):
+        z, e = np.float32(0.05 * k), np.float32(0.6 + 0.01 * k)
+        v = np.array([[-e, -e, z, 0, 0, -1, 0, 0], [e, -e, z, 0, 0, -1, 1, 0], [e, e, z, 0, 0, -1, 1, 1], [-e, e, z, 0, 0, -1, 0, 1]], np.float32)
+        last = k == layers
+        s.add_mesh(v, quad, (0.2 + 0.6 * (k % 3 == 0), 0.2 + 0.6 * (k % 3 == 1), 0.2 + 0.6 * (k % 3 == 2), 0, 0, 0, 1, 1.0 if last else alpha))
+    s.lights.append(abi.point_light((0.3, 0.4, -2.0), (1, 1, 1)))
+    return s
+
+
+def test_transparency_chain_of_sixteen_layers_and_its_reported_limit(gpu_device):
+    """renderRayTracingTransparency recurses once per translucent surface without a bound
+    (src/transparency.cpp:6-20); the device keeps 16 layers per camera ray.  16 layers in
+    front of an opaque surface must give the oracle's frame; a 17th is taken as opaque and
+    the affected camera rays are reported in rtx_stats.layer_overflows instead of passing
+    silently."""
+    f = abi.features(**cases.BASE)
+    cam = make_camera(rotation_degrees=(0, 0, 0), distance=3.0)
+    rp = make_params(48, 40, driver=abi.DRIVER_TRANSPARENCY)
+    for layers in (3, 16):
+        scene = _stacked_quads(layers)
+        gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+        got, want = gpu.render(cam, f, rp), orc.render(cam, f, rp)
+        assert gpu.stats.layer_overflows == 0
+        assert (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce) == tuple(int(x) for x in orc.counters[:3])
+        assert gpu.stats.rays_primary >= 48 * 40 + 200 * layers          # the chains were followed
+        assert_images_close(got, want, f"{layers} translucent layers")
+        gpu.close()
+        orc.close()
+    scene = _stacked_quads(17)
+    gpu = GpuEngine(scene, f)
+    gpu.render(cam, f, rp)
+    assert gpu.stats.layer_overflows > 0
     gpu.close()
 
 

@@ -183,6 +183,18 @@ def test_bad_triangle_index_is_rejected():
         s.add_mesh(np.zeros((3, 8), np.float32), [[0, 1, 3]])
 
 
+def test_non_finite_vertices_are_rejected_by_the_flattener():
+    """A NaN or infinite position (a damaged OBJ) would leave the sweep-split builder with NaN
+    costs and an empty half; the host layer refuses the scene instead (the reference's behaviour
+    is undefined there)."""
+    for bad in (np.nan, np.inf):
+        for sah in (0, 1):
+            s = cases.load_scene("cube")
+            s.meshes[0].vertices[2, 1] = bad
+            with pytest.raises(RuntimeError, match="not finite"):
+                engine.flatten(s, abi.features(accel_structure=1, bvh_sah_binning=sah))
+
+
 def test_scene_npz_round_trip_and_seeded_standin(tmp_path):
     a = cases.load_scene("cornell_parallelogram")
     a.set_envmap(cases.env_image(), abi.ENV_CYLINDRICAL, 120.0, (0.1, 0.2, 0.3))
