@@ -1,5 +1,6 @@
 # Builds every native piece in-tree:
 #   raytracer_amd/librtx_hip.so    HIP kernels + C ABI (include/rtx.h), gfx950
+#   raytracer_amd/libvalu_peak.so  VALU issue-rate microbenchmark (diagnostic, used by bench.py)
 #   raytracer_amd/librtx_host.so   C++ host side: reference-shaped API, BVH builder, flattener
 #   oracle/liboracle.so (+ oracle/_ref/libref.so where /root/reference exists)   test infrastructure
 HIPCC    ?= /opt/rocm/bin/hipcc
@@ -16,7 +17,10 @@ HOST_HDR := $(wildcard raytracer_amd/host/*.h) include/rtx.h
 .PHONY: all hip host examples oracle clean
 all: hip host examples oracle
 
-hip: raytracer_amd/librtx_hip.so
+hip: raytracer_amd/librtx_hip.so raytracer_amd/libvalu_peak.so
+# diagnostic beside the product library: what a SIMD's vector ALU issues per cycle (bench.py's VALU roofline)
+raytracer_amd/libvalu_peak.so: tools/valu_peak.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -shared -o $@ tools/valu_peak.hip
 raytracer_amd/librtx_hip.so: raytracer_amd/csrc/rtx_hip.hip raytracer_amd/csrc/rtx_device.hpp include/rtx.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ raytracer_amd/csrc/rtx_hip.hip
 
@@ -33,5 +37,5 @@ oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f raytracer_amd/librtx_hip.so raytracer_amd/librtx_host.so
+	rm -f raytracer_amd/librtx_hip.so raytracer_amd/librtx_host.so raytracer_amd/libvalu_peak.so
 	$(MAKE) -C oracle clean

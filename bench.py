@@ -81,6 +81,26 @@ def cpu_baseline(scene, features, cam, args):
                        f"({'reference renderRayTracingMRaysPerPixel, OpenMP' if kind == 'reference' else 'CPU restatement, OpenMP'})"), n_aabb, n_tri
 
 
+def valu_peak(waves_per_simd=4):
+    """Vector-ALU issue rate of this GPU, measured now: wave-instructions per second chip-wide
+    for the traversal loop's instruction mix at the render kernel's occupancy, and per cycle per
+    SIMD for that mix and for plain v_mul_f32 (the fastest kind).  None if the diagnostic
+    library was not built."""
+    so = os.path.join(ROOT, "raytracer_amd", "libvalu_peak.so")
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    lib.valu_peak_run.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    out = (C.c_double * 4)()
+    if lib.valu_peak_run(lib.valu_peak_mix_kind(), waves_per_simd, 4000, out) != 0:
+        return None
+    res = dict(ipc=out[0], clock_mhz=out[2], chip_ginstr_s=out[3] / 1e9)
+    if lib.valu_peak_run(0, waves_per_simd, 4000, out) != 0:
+        return None
+    res["ipc_mul"] = out[0]
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +115,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-GPU render of it")
-    ap.add_argument("--every-block", action="store_true", help="also time the frame with no block declared unable to see the scene (adds roofline.kernel_ms_every_block_traced)")
+    ap.add_argument("--no-every-block", action="store_true", help="skip the second timing of the frame with no block declared unable to see the scene (roofline.kernel_ms_every_block_traced)")
     ap.add_argument("--force-pipeline", action="store_true", help="rehearsal: run the N > 1 code path (tiles, gather, assembly) in a one-rank group")
     args = ap.parse_args()
 
@@ -178,7 +198,7 @@ def main():
     if pipe is not None:
         pipe.drain()
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the small reductions live
-    counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce, st.shaded_hits], dtype=torch.float64, device=red_dev)
+    counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce, st.shaded_hits, st.rays_traced], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(counts)
     rays_frame = float(counts[:3].sum())
@@ -208,7 +228,7 @@ def main():
     # for the record: the same frame with every block traced (no block is declared
     # unable to see the scene; each of its camera rays then fails the root box test)
     traced_all_ms = None
-    if not grouped and args.every_block:
+    if not grouped and not args.no_every_block:
         os.environ["RTX_NO_CULL"] = "1"
         best = 1e9
         for _ in range(4):
@@ -217,6 +237,7 @@ def main():
             best = min(best, s2.kernel_ms)
         del os.environ["RTX_NO_CULL"]
         assert (s2.rays_primary, s2.rays_shadow) == (st.rays_primary, st.rays_shadow)
+        assert s2.rays_traced >= st.rays_traced
         traced_all_ms = best
 
     if rank == 0 and args.check and grouped:
@@ -237,6 +258,10 @@ def main():
                                    f"{args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light, sweep-split BVH "
                                    f"({gpu.levels()} levels, {gpu.leaves()} leaves)",
                        "rays_per_frame": int(rays_frame), "primary": int(counts[0]), "shadow": int(counts[1]),
+                       # one "ray" = one BvhInterface::intersect call of the reference.  The device does not make
+                       # the camera rays of 8x8 blocks that cannot see the scene's bounds (the reference tests
+                       # and misses them): rays_traced are the rays that did walk the scene on the device
+                       "rays_traced": int(counts[4]), "value_on_rays_traced": round(float(counts[4]) * args.steps / elapsed / 1e6, 2),
                        "partition": "whole frame" if not grouped else f"interleaved {args.tile}x{args.tile} tiles + RCCL gather to rank 0",
                        "bvh_build_upload_s": round(t_build, 3)},
         }
@@ -244,11 +269,16 @@ def main():
             cb, n_aabb, n_tri = (None, None, None)
             if not args.no_cpu_baseline:
                 cb, n_aabb, n_tri = cpu_baseline(scene, features, cam_in, args)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            # measured counters of the same command, committed with the rocprofv3 summaries they come from
+            traffic, valu_instr = None, None
+            tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as fh:
                     traffic = json.load(fh).get("bytes_per_launch")
+            cpath = os.path.join(ROOT, "profiles", "r02_render_counters.json")
+            if os.path.exists(cpath):
+                with open(cpath) as fh:
+                    valu_instr = json.load(fh).get("counters_per_launch_mean", {}).get("SQ_INSTS_VALU")
             if n_aabb is not None:
                 alg = algorithmic_bytes(rays_frame, shaded_frame, pixels, n_aabb, n_tri)
                 achieved = alg / (kernel_ms * 1e-3) / 1e9
@@ -257,8 +287,22 @@ def main():
                                    "kernel": "renderKernel", "kernel_ms": round(kernel_ms, 4),
                                    "algorithmic_bytes_per_launch": int(alg), "box_tests_per_ray": round(n_aabb, 3),
                                    "tri_tests_per_ray": round(n_tri, 3)}
+                if traffic is not None:
+                    # what the kernel really moves to and from memory: the scene is cache-resident, so
+                    # this, not the algorithmic figure, is the kernel's place on the HBM roofline
+                    out["roofline"]["frac_measured"] = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 if traced_all_ms is not None:
                     out["roofline"]["kernel_ms_every_block_traced"] = round(traced_all_ms, 4)
+                    out["roofline"]["mrays_s_every_block_traced"] = round(rays_frame / traced_all_ms / 1e3, 1)
+            if valu_instr is not None:
+                vp = valu_peak()
+                if vp is not None:
+                    achieved = valu_instr / (kernel_ms * 1e-3) / 1e9
+                    out["roofline_valu"] = {"bound": "valu issue", "achieved": round(achieved, 1), "peak": round(vp["chip_ginstr_s"], 1), "unit": "G wave-instr/s",
+                                            "frac": round(achieved / vp["chip_ginstr_s"], 4), "valu_instr_per_launch": int(valu_instr),
+                                            "peak_is": "measured now on this GPU: the traversal loop's instruction mix (tools/valu_peak.hip) at the kernel's 4 waves per SIMD",
+                                            "peak_instr_per_cycle_per_simd": round(vp["ipc"], 4), "peak_v_mul_f32_instr_per_cycle_per_simd": round(vp["ipc_mul"], 4),
+                                            "clock_mhz": round(vp["clock_mhz"])}
             if cb is not None:
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

@@ -542,6 +542,54 @@ def test_dragon_standin_full_size_properties(gpu_device):
     gpu.close()
 
 
+def _glossy_dragon():
+    """BASELINE configs[2] on the stand-in: one parallelogram light above the mesh, every
+    surface glossy (ks = 0.5, shininess 50)."""
+    scene = dragon_scene()
+    scene.lights = [abi.parallelogram_light((-0.2, 0.9, 0.0), (0.4, 0, 0), (0, 0, 0.4), (1, 1, 1), (1, 0.9, 0.8), (0.8, 0.9, 1), (1, 1, 1))]
+    for m in scene.meshes:
+        m.material[3:6] = 0.5
+        m.material[6] = 50.0
+    return scene
+
+
+def test_dragon_standin_area_light_glossy_depth_four(gpu_device):
+    """BASELINE configs[2]: area light with 64 shadow samples + glossy reflections (5 rays) to
+    depth 4, on the dragon stand-in.  Against the oracle at 96x54 (frame and ray counts); at
+    the full 1920x1080 through properties that need no oracle: two runs identical, primary =
+    W*H, 64 shadow rays per shaded point, every bounce ray belongs to a shaded parent."""
+    scene = _glossy_dragon()
+    f = abi.features(**dict(cases.BASE, hard_shadow=0, soft_shadow=1, recursive=1, glossy_reflection=1))
+    cam = make_camera()
+    kw = dict(shadow_samples=64, glossy_rays=5, ray_depth=4)
+    gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+    small = make_params(96, 54, **kw)
+    got = gpu.render(cam, f, small)
+    rays_gpu = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
+    want = orc.render(cam, f, small)
+    assert rays_gpu == tuple(int(x) for x in orc.counters[:3])
+    assert rays_gpu[2] > rays_gpu[0] // 20 and rays_gpu[1] == 64 * gpu.stats.shaded_hits
+    assert_images_close(got, want, "dragon stand-in, area light 64 + glossy depth 4, 96x54")
+    # the same features at depth 2 through the multi-sample driver (4 camera samples per pixel share a wave)
+    mr = make_params(48, 27, driver=abi.DRIVER_MRAYS, samples=4, shadow_samples=64, glossy_rays=5, ray_depth=2)
+    assert_images_close(gpu.render(cam, f, mr), orc.render(cam, f, mr), "dragon stand-in, area light 64 + glossy depth 2, 4 spp")
+    orc.close()
+    full = make_params(1920, 1080, **kw)
+    a = gpu.render(cam, f, full)
+    s = gpu.stats
+    first = (s.rays_primary, s.rays_shadow, s.rays_bounce, s.shaded_hits)
+    assert s.rays_primary == 1920 * 1080
+    assert s.rays_shadow == 64 * s.shaded_hits
+    # every shaded point belongs to a camera ray or a bounce ray that hit; a point spawns at most 5 bounce rays
+    assert s.shaded_hits <= s.rays_primary + s.rays_bounce and s.rays_bounce <= 5 * s.shaded_hits
+    assert s.rays_bounce > s.rays_primary // 20
+    b = gpu.render(cam, f, full)
+    t = gpu.stats
+    assert (t.rays_primary, t.rays_shadow, t.rays_bounce, t.shaded_hits) == first
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b)), "two renders of the same frame differ"
+    gpu.close()
+
+
 def test_multi_rank_code_path_through_rccl_on_one_gpu(gpu_device):
     """bench.py's N > 1 path (this rank's tiles -> RCCL gather on the collective's
     stream, overlapped with the next frame's render -> de-tiling) run as a one-rank
@@ -638,6 +686,86 @@ def test_tree_deeper_than_sixteen_levels(gpu_device):
     assert_hits_equal(gpu.intersect(rays, f), orc.intersect(rays, f), "six instances, primary rays")
     gpu.close()
     orc.close()
+
+
+def test_instanced_scene_features_of_config_five_against_the_oracle(gpu_device):
+    """BASELINE configs[4]'s features on a multi-instance scene small enough for the oracle: 27
+    instances (every third one translucent) through the depth-of-field, motion-blur and
+    transparency drivers and the jittered one, frames and ray counts."""
+    from raytracer_amd.scene import instanced_scene
+    scene = instanced_scene(27, subdivisions=3)          # 27 x 1280 triangles
+    f = abi.features(**cases.BASE)
+    cam = make_camera(distance=1.6)
+    moved = make_camera(distance=1.6, look_at=(0, 0, 0.3))
+    gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+    for name, rp in (("jittered 16 spp", make_params(160, 90, driver=abi.DRIVER_MRAYS, samples=16)),
+                     ("depth of field, 4 lens samples", make_params(160, 90, driver=abi.DRIVER_DOF, samples=4, aperture=0.1, focal_length=2.0)),
+                     ("motion blur, 7 steps", make_params(160, 90, driver=abi.DRIVER_MOTION_BLUR, samples=7, prev_camera=moved)),
+                     ("transparency", make_params(160, 90, driver=abi.DRIVER_TRANSPARENCY))):
+        got = gpu.render(cam, f, rp)
+        rays_gpu = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
+        want = orc.render(cam, f, rp)
+        assert rays_gpu == tuple(int(x) for x in orc.counters[:3]), name
+        assert gpu.stats.layer_overflows == 0
+        assert_images_close(got, want, "27 instances, " + name)
+    assert gpu.stats.rays_primary > 160 * 90        # translucent instances were looked through
+    gpu.close()
+    orc.close()
+
+
+def test_ten_million_triangles_at_3840x2160(gpu_device):
+    """BASELINE configs[4] at full size: 122 instances = 9 994 240 triangles (a 22-level tree,
+    the 24-entry stack), 3840x2160.  The oracle cannot render this in seconds, so: primary rays
+    through every 40th pixel corner against the oracle (hit, distance, triangle, attributes
+    bit-exact), and per driver the properties that need no oracle -- two runs identical,
+    primary = W*H*samples, one shadow ray per shaded point, the two halves of an interleaved-tile
+    partition reassemble the frame."""
+    import ctypes as C
+    from raytracer_amd import engine
+    from raytracer_amd.engine import host_lib, _ptr
+    from raytracer_amd.scene import instanced_scene
+    W, H = 3840, 2160
+    scene = instanced_scene(122)
+    assert scene.n_triangles == 9994240
+    f = abi.features(**cases.BASE)
+    cam = make_camera()
+    gpu = GpuEngine(scene, f)
+    assert gpu.levels() > 16
+    moved = make_camera(look_at=(0, 0, 0.3))
+    frames = {}
+    for name, rp, per_pixel in (("jittered 16 spp", make_params(W, H, driver=abi.DRIVER_MRAYS, samples=16), 16),
+                                ("depth of field", make_params(W, H, driver=abi.DRIVER_DOF, samples=4), 4),
+                                ("motion blur", make_params(W, H, driver=abi.DRIVER_MOTION_BLUR, samples=7, prev_camera=moved), 7),
+                                ("transparency", make_params(W, H, driver=abi.DRIVER_TRANSPARENCY), 0)):
+        a = gpu.render(cam, f, rp)
+        s = gpu.stats
+        first = (s.rays_primary, s.rays_shadow, s.rays_bounce, s.shaded_hits)
+        if per_pixel:
+            assert s.rays_primary == W * H * per_pixel, name
+        else:
+            assert s.rays_primary > W * H and s.layer_overflows == 0, name   # layers behind translucent instances
+        assert s.rays_shadow == s.shaded_hits and s.rays_bounce == 0 and 0 < s.rays_traced <= s.rays_primary + s.rays_shadow, name
+        b = gpu.render(cam, f, rp)
+        t = gpu.stats
+        assert (t.rays_primary, t.rays_shadow, t.rays_bounce, t.shaded_hits) == first, name
+        assert np.array_equal(a, b), name + ": two renders of the same frame differ"
+        assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() > 0.0, name
+        frames[name] = a
+        del b
+    # interleaved tiles of two ranks into one buffer = the whole frame
+    acc = np.full((H, W, 3), -7.0, np.float32)
+    for rank in range(2):
+        rp = make_params(W, H, driver=abi.DRIVER_MRAYS, samples=16, tile_rank=rank, tile_world=2)
+        assert host_lib().rtxh_render(C.c_void_p(gpu.b), C.byref(cam), C.byref(f), C.byref(rp), _ptr(acc), C.byref(gpu.stats)) == 0
+    assert np.array_equal(acc, frames["jittered 16 spp"]), "tiles of two ranks do not assemble the single-GPU frame"
+    del acc, frames
+    rays = engine.camera_rays(cam, W, H, step=40)
+    got = gpu.intersect(rays, f)
+    gpu.close()
+    orc = OracleEngine(scene, f)
+    ties = assert_hits_equal(got, orc.intersect(rays, f), "10 M triangles, primary rays")
+    orc.close()
+    assert ties == 0 and got["hit"].sum() > len(rays) // 20
 
 
 def test_counting_kernel_builds_give_the_same_frames(gpu_device, monkeypatch):
