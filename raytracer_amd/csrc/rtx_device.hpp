@@ -59,6 +59,13 @@ struct DScene {
     const float4* nodes;     // 4 x float4 per rtx_node; the array's start
     const float4* tris;      // 4 x float4 per rtx_tri (leaf order) = nodes + 4 * nNodes
     int32_t nNodes;
+    // The same tree for the wave-shared walk (traverseBvhWave), read through the scalar cache:
+    // per inner node 8 x float4 = per axis (lo0, lo1, hi0, hi1) and its mirror image
+    // (-hi0, -hi1, -lo0, -lo1), then the two child references; per triangle (leaf order)
+    // 6 x float4 = (n, D), (v0, id word), (v1, -), v2 - v0, v2 - v1, v1 - v0.
+    const float4* waveNodes;
+    const float4* waveTris;
+    int32_t boxesNested;     // every child box lies within its parent's box, the root's children within the root box
     const float4* attrs;     // 4 x float4 per rtx_tri_attr
     const int32_t* idOrder;  // leaf-order record index of triangle id i (brute-force path)
     const rtx_material* mats;
@@ -436,6 +443,215 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
     }
 }
 
+// ------------------------------------------------- wave-shared traversal ----
+// The 64 rays of a wave walked through the tree TOGETHER: one node or one triangle
+// at a time for the whole wave, its record fetched once through the scalar cache
+// into scalar registers, one stack of (subtree, per-lane key) entries.  Every lane
+// still decides for itself, with the reference's predicates evaluated on its own ray
+// (childTestFinite's arithmetic, triangleTest's arithmetic), which subtrees it takes
+// part in: a lane is active below a node only if it passed the visit test of every
+// box on the way, and sits a subtree out otherwise.  So each lane tests exactly the
+// boxes and triangles it could test walking alone; only the ORDER is the wave's
+// (children by majority vote of the lanes that enter both), which matters only for
+// exact-t ties between triangles, as for the depth-first order itself.
+// What it buys on coherent rays (camera samples of neighbouring pixels, shadow rays
+// of one light towards neighbouring points): no trip serves some lanes' boxes and
+// other lanes' triangles at once, addressing / stack / loop control are scalar, a
+// triangle whose plane no lane meets in range is dropped after a third of its test,
+// and no vector registers or vector memory instructions are spent on the records.
+//
+// The rays of one call share the signs of their direction components (`oct`, bit a
+// set: component a negative).  The walk then runs in the mirror image in which all
+// three are positive: a node's record holds, per axis, the planes (lo, hi) and the
+// mirrored planes (-hi, -lo), the origin is mirrored likewise, and |1/d| is used.
+// Negation is exact, so (lo' - o') * |1/d| are the very numbers (lo - o) * (1/d) and
+// (hi - o) * (1/d), already in the order min/max would put them: the per-axis
+// ordering of the slab test costs nothing.
+// (the compiler's own ballot on a condition: no detour through a 0 / 1 integer per lane)
+RTX_DEV uint64_t laneMask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+RTX_DEV bool anyLane(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; }
+typedef float NF4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const NF4 UniformF4; // constant address space: uniform addresses load through the scalar cache
+RTX_DEV const UniformF4* uniformRecords(const float4* p) { return (const UniformF4*)(uintptr_t)p; }
+constexpr int kWaveNodeQuads = 8, kWaveTriQuads = 6;
+
+// How a call of the wave-shared walk tests boxes:
+//   BOX_MIRRORED  childTestFinite's arithmetic in the mirrored frame (finite 1/d, one octant)
+//   BOX_OUTSIDE   the same for rays that start outside the root box, hence outside every box of
+//                 a tree whose boxes are nested (checked at upload): "origin inside the box" is
+//                 false throughout and is not evaluated
+//   BOX_LITERAL   the comparison-by-comparison slab test on the unmirrored planes, for rays with
+//                 an infinite reciprocal direction component (0 * inf = NaN must fall through
+//                 the comparisons exactly as in the reference); any mix of octants
+enum BoxMode { BOX_MIRRORED = 0, BOX_OUTSIDE = 1, BOX_LITERAL = 2 };
+
+// childTestFinite for one child in the mirrored frame: lo <= hi per axis and im > 0, so
+// t0 = (lo - o) * im <= t1 = (hi - o) * im already.
+template <int MODE>
+RTX_DEV void childTestMirrored(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im, float tmax, bool& h, float& key)
+{
+    const float dlx = lox - om.x, dly = loy - om.y, dlz = loz - om.z;
+    const float dhx = hix - om.x, dhy = hiy - om.y, dhz = hiz - om.z;
+    const float t0x = dlx * im.x, t0y = dly * im.y, t0z = dlz * im.z;
+    const float t1x = dhx * im.x, t1y = dhy * im.y, t1z = dhz * im.z;
+    float first = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
+    const float second = fminf(fminf(t1x, t1y), t1z);
+    const bool miss = first > second;
+    if (first <= 0.0f)
+        first = second;
+    if (MODE == BOX_OUTSIDE) {
+        key = first;
+        h = !miss && !(tmax < first);
+    } else {
+        const bool in = fmaxf(fmaxf(dlx, dly), dlz) <= 0.0f && fminf(fminf(dhx, dhy), dhz) >= 0.0f;
+        key = in ? 0.0f : first;
+        h = in || (!miss && !(tmax < first));
+    }
+}
+
+// `alive`: the lanes of this call (passed the root box; for the mirrored modes: same octant,
+// finite 1/d).  t and bestK as in traverseBvh; with EARLY a lane stops taking part once it
+// knows a hit below tStop.
+template <int STACK, bool COUNT, bool EARLY, int MODE>
+RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, V3 inv, bool alive, uint32_t oct, float& t, int& bestK, TraceCounters& tc, float tStop)
+{
+    const bool nx = MODE != BOX_LITERAL && (oct & 1u) != 0, ny = MODE != BOX_LITERAL && (oct & 2u) != 0, nz = MODE != BOX_LITERAL && (oct & 4u) != 0; // wave-uniform
+    const V3 om = mk(nx ? -o.x : o.x, ny ? -o.y : o.y, nz ? -o.z : o.z);
+    const V3 im = MODE == BOX_LITERAL ? inv : mk(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z));
+    const UniformF4* const nodes = uniformRecords(sc.waveNodes);
+    const UniformF4* const tris = uniformRecords(sc.waveTris);
+    const int qx = nx ? 1 : 0, qy = ny ? 3 : 2, qz = nz ? 5 : 4;
+    int sp = 0;
+    int32_t cur = __builtin_amdgcn_readfirstlane(sc.rootRef);
+    bool act = alive;
+    if (!anyLane(act))
+        return;
+    for (;;) {
+        if (cur >= 0) {
+            const UniformF4* p = nodes + size_t(uint32_t(cur)) * kWaveNodeQuads;
+            const NF4 X = p[qx], Y = p[qy], Z = p[qz], R = p[6];
+            bool h0, h1;
+            float k0, k1;
+            if (MODE == BOX_LITERAL) {
+                h0 = childTest(mk(X.x, Y.x, Z.x), mk(X.z, Y.z, Z.z), o, inv, t, k0);
+                h1 = childTest(mk(X.y, Y.y, Z.y), mk(X.w, Y.w, Z.w), o, inv, t, k1);
+            } else {
+                childTestMirrored<MODE>(X.x, Y.x, Z.x, X.z, Y.z, Z.z, om, im, t, h0, k0);
+                childTestMirrored<MODE>(X.y, Y.y, Z.y, X.w, Y.w, Z.w, om, im, t, h1, k1);
+            }
+            if (COUNT)
+                tc.boxTests += act ? 2u : 0u;
+            h0 = h0 && act;
+            h1 = h1 && act;
+            const uint64_t b0 = laneMask(h0), b1 = laneMask(h1);
+            const int32_t r0 = __builtin_amdgcn_readfirstlane(__float_as_int(R.x)), r1 = __builtin_amdgcn_readfirstlane(__float_as_int(R.y));
+            if (b0 && b1) {
+                // nearer child first, by the vote of the lanes that enter any: a lane votes for
+                // child 1 if that is the only one it enters, or the nearer of its two
+                const uint64_t for1 = laneMask(h1 && (!h0 || k1 < k0));
+                const bool firstIs1 = 2 * __popcll(for1) > __popcll(b0 | b1);
+                const float inf = __builtin_inff();
+                st.push(sp++, firstIs1 ? r0 : r1, firstIs1 ? (h0 ? k0 : inf) : (h1 ? k1 : inf)); // (an infinite key: not this lane's subtree)
+                cur = firstIs1 ? r1 : r0;
+                act = firstIs1 ? h1 : h0;
+                continue;
+            }
+            if (b0 | b1) {
+                cur = b0 ? r0 : r1;
+                act = b0 ? h0 : h1;
+                continue;
+            }
+        } else {
+            // a leaf: its triangles one after the other, for the lanes that entered it
+            uint32_t k = uint32_t(~cur) - uint32_t(sc.nNodes);
+            for (;;) {
+                const UniformF4* q = tris + size_t(k) * kWaveTriQuads;
+                const NF4 P = q[0], A = q[1];
+                const bool last = __float_as_int(A.w) < 0; // (top bit of the id word)
+                if (COUNT)
+                    tc.triTests += act ? 1u : 0u;
+                // the plane part of triangleTest
+                const float dn = P.x * d.x + P.y * d.y + P.z * d.z;
+                const float no = P.x * o.x + P.y * o.y + P.z * o.z;
+                const float th = (P.w - no) / dn;
+                bool ok = act && !(dn == 0.f) && !(th <= 0.f) && (th < t);
+                if (anyLane(ok)) {
+                    const NF4 B = q[2], E0 = q[3], E1 = q[4], C = q[5];
+                    const V3 n = mk(P.x, P.y, P.z);
+                    const V3 pt = o + th * d;
+                    const V3 e0 = pt - mk(A.x, A.y, A.z), e1 = pt - mk(B.x, B.y, B.z);
+                    const float alpha = dot(n, cross(mk(E1.x, E1.y, E1.z), e1));
+                    const float beta = dot(n, cross(e0, mk(E0.x, E0.y, E0.z)));
+                    const float gamma = dot(n, cross(mk(C.x, C.y, C.z), e0));
+                    ok = ok && !(alpha < 0 || beta < 0 || gamma < 0);
+                    if (ok) {
+                        t = th;
+                        bestK = int(k);
+                        if (EARLY && t < tStop) {
+                            alive = false;
+                            act = false;
+                        }
+                    }
+                }
+                if (last || !anyLane(act))
+                    break;
+                k++;
+            }
+        }
+        bool have = false;
+        while (sp > 0) {
+            int32_t r;
+            float key;
+            st.pop(--sp, r, key);
+            act = alive && !(t < key);
+            if (anyLane(act)) {
+                cur = __builtin_amdgcn_readfirstlane(r);
+                have = true;
+                break;
+            }
+        }
+        if (!have)
+            break;
+    }
+}
+
+// Closest hits of the wave's rays (`lane`: this lane has one) by the wave-shared walk: one
+// pass per direction octant present among them, and one for the rays whose reciprocal
+// direction is not finite (axis-parallel rays).  t, bestK, tStop, rootLimit as in
+// traverseBvh.  Must be called by all lanes of the wave together.
+template <int STACK, bool COUNT, bool EARLY>
+RTX_DEV void traverseWaveTogether(const DScene& sc, LaneStack<STACK>& st, bool lane, V3 o, V3 d, float& t, int& bestK, TraceCounters& tc, float tStop = 0.f, float rootLimit = 0.f)
+{
+    bestK = -1;
+    if (sc.rootRef == kEmptyRoot)
+        return;
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool finiteInv = fabsf(inv.x) < __builtin_inff() && fabsf(inv.y) < __builtin_inff() && fabsf(inv.z) < __builtin_inff();
+    bool in = lane;
+    if (in) {
+        // the root box, as in traverseBvh
+        float key;
+        if (COUNT)
+            tc.boxTests++;
+        in = slab(mk(sc.rootLo), mk(sc.rootHi), o, inv, EARLY ? rootLimit : t, key);
+    }
+    // a ray that starts outside the root box starts outside every box of a nested tree
+    const bool outside = sc.boxesNested && !inBox(mk(sc.rootLo), mk(sc.rootHi), o);
+    const uint32_t myOct = (inv.x < 0.f ? 1u : 0u) | (inv.y < 0.f ? 2u : 0u) | (inv.z < 0.f ? 4u : 0u);
+    uint64_t rest = laneMask(in && finiteInv);
+    while (rest) {
+        const uint32_t oct = uint32_t(__builtin_amdgcn_readlane(int(myOct), __builtin_ctzll(rest)));
+        const bool mine = in && finiteInv && myOct == oct;
+        if (!anyLane(mine && !outside))
+            traverseBvhWave<STACK, COUNT, EARLY, BOX_OUTSIDE>(sc, st, o, d, inv, mine, oct, t, bestK, tc, tStop);
+        else
+            traverseBvhWave<STACK, COUNT, EARLY, BOX_MIRRORED>(sc, st, o, d, inv, mine, oct, t, bestK, tc, tStop);
+        rest &= ~laneMask(mine);
+    }
+    if (anyLane(in && !finiteInv))
+        traverseBvhWave<STACK, COUNT, EARLY, BOX_LITERAL>(sc, st, o, d, inv, in && !finiteInv, 0u, t, bestK, tc, tStop);
+}
+
 // Brute-force path (features.enableAccelStructure == false),
 // src/bounding_volume_hierarchy.cpp:330-360: every triangle in scene order,
 // with the extra `t > 1e-6` acceptance rule.
@@ -577,6 +793,58 @@ RTX_DEV bool intersectScene(const DScene& sc, LaneStack<STACK>& st, const rtx_fe
     int bestK, sphere;
     V3 sphereN;
     const bool any = closestHit<STACK, COUNT>(sc, st, f, o, d, t, bestK, sphere, sphereN, tc);
+    hitAttributes(sc, f, o, d, t, bestK, sphere, sphereN, hit);
+    return any;
+}
+
+// closestHit / lightVisibility / intersectScene for a whole wave at once (`lane`: this lane
+// has a query), with the triangles found by the wave-shared walk.  Same results per lane.
+template <int STACK, bool COUNT, bool EARLY = false>
+RTX_DEV bool closestHitWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 o, V3 d, float& t, int& bestK, int& sphere, V3& sphereN, TraceCounters& tc, float tStop = 0.f, float clip = 0.f)
+{
+    sphere = -1;
+    sphereN = mk(0, 0, 0);
+    bestK = -1;
+    if (lane)
+        for (int i = 0; i < sc.nSpheres; i++) {
+            V3 n;
+            if (sphereTest(sc.spheres[i], o, d, t, n)) {
+                sphereN = n;
+                sphere = i;
+            }
+        }
+    const float afterSpheres = t;
+    if (EARLY)
+        t = (clip < t) ? clip : t;
+    if (f.enable_accel_structure)
+        traverseWaveTogether<STACK, COUNT, EARLY>(sc, st, lane, o, d, t, bestK, tc, tStop, afterSpheres);
+    else if (lane)
+        traverseAll<COUNT>(sc, o, d, t, bestK, tc);
+    return lane && (bestK >= 0 || sphere >= 0);
+}
+template <int STACK, bool COUNT>
+RTX_DEV float lightVisibilityWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 pos, V3 hp, TraceCounters& tc)
+{
+    const V3 sd = hp - pos;
+    const float len = length(sd);
+    const float scale = fmaxf(fmaxf(fmaxf(fabsf(hp.x), fabsf(hp.y)), fabsf(hp.z)), fmaxf(fmaxf(fabsf(pos.x), fabsf(pos.y)), fabsf(pos.z)));
+    float ts = kFltMax, clip = kFltMax, tStop = -__builtin_inff();
+    if (len >= 0.2f && scale <= 64.0f) {
+        clip = 1.01f;
+        tStop = 1.0f - 4e-3f / len;
+    }
+    int bk, sph;
+    V3 sn;
+    closestHitWave<STACK, COUNT, true>(sc, st, f, lane, pos, sd, ts, bk, sph, sn, tc, tStop, clip);
+    const V3 second = pos + ts * sd;
+    return (double(distance(hp, second)) > 1e-3) ? 0.0f : 1.0f;
+}
+template <int STACK, bool COUNT>
+RTX_DEV bool intersectSceneWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 o, V3 d, float& t, Hit& hit, TraceCounters& tc)
+{
+    int bestK, sphere;
+    V3 sphereN;
+    const bool any = closestHitWave<STACK, COUNT>(sc, st, f, lane, o, d, t, bestK, sphere, sphereN, tc);
     hitAttributes(sc, f, o, d, t, bestK, sphere, sphereN, hit);
     return any;
 }

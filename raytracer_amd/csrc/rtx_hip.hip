@@ -50,12 +50,12 @@ struct LaneCounters {
     uint32_t traced = 0;   // counted rays that did walk the scene (not: rays of blocks that cannot see it, light samples behind the surface)
     uint32_t overflow = 0; // camera samples whose transparency chain was cut at kMaxLayers
     TraceCounters tc { 0, 0 };
-    RTX_DEV void countPrimary(bool lane) { primary += __popcll(__ballot(lane)); }
-    RTX_DEV void countShadow(bool lane) { shadow += __popcll(__ballot(lane)); }
-    RTX_DEV void countBounce(bool lane) { bounce += __popcll(__ballot(lane)); }
-    RTX_DEV void countShaded(bool lane) { shaded += __popcll(__ballot(lane)); }
-    RTX_DEV void countTraced(bool lane) { traced += __popcll(__ballot(lane)); }
-    RTX_DEV void countOverflow(bool lane) { overflow += __popcll(__ballot(lane)); }
+    RTX_DEV void countPrimary(bool lane) { primary += __popcll(laneMask(lane)); }
+    RTX_DEV void countShadow(bool lane) { shadow += __popcll(laneMask(lane)); }
+    RTX_DEV void countBounce(bool lane) { bounce += __popcll(laneMask(lane)); }
+    RTX_DEV void countShaded(bool lane) { shaded += __popcll(laneMask(lane)); }
+    RTX_DEV void countTraced(bool lane) { traced += __popcll(laneMask(lane)); }
+    RTX_DEV void countOverflow(bool lane) { overflow += __popcll(laneMask(lane)); }
 };
 
 #ifdef RTX_PROBE
@@ -1023,8 +1023,7 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
     bool any = false;
     lc.countPrimary(active);
     lc.countTraced(active);
-    if (active)
-        any = intersectScene<STACK, COUNT>(sc, st, f, o, d, t, hit, lc.tc);
+    any = intersectSceneWave<STACK, COUNT>(sc, st, f, active, o, d, t, hit, lc.tc);
     const bool shade = any && f.enable_shading;
     lc.countShaded(shade);
     V3 hp = mk(0, 0, 0), hitN = mk(0, 0, 0), albedo = mk(0, 0, 0), ks = mk(0, 0, 0), visN = mk(0, 0, 0);
@@ -1055,8 +1054,9 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
             lc.countShadow(shade);
             const bool facing = shade && lightFacesSurface(pos, hp, visN);
             lc.countTraced(facing);
+            const float visible = lightVisibilityWave<STACK, COUNT>(sc, st, f, facing, pos, hp, lc.tc);
             if (shade)
-                sh = sh * (facing ? lightVisibility<STACK, COUNT>(sc, st, f, pos, hp, visN, lc.tc) : 0.0f);
+                sh = sh * (facing ? visible : 0.0f);
         }
         if (shade)
             result = result + sh;
@@ -1601,7 +1601,7 @@ struct rtx_scene {
     int device = -1;
     int refs = 1;
     DScene d {};
-    void* buffers[12] = {};
+    void* buffers[16] = {};
     int nBuffers = 0;
     int numLevels = 0;
     bool hasEnv = false;
@@ -2452,6 +2452,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     }
     const bool emptyTree = d->root_ref == INT32_MIN;
     int walkedLevels = 0; // inner nodes on the longest path from the root, plus the leaf
+    bool boxesNested = true; // (NaN planes make it false)
     if (!emptyTree) {
         auto refOk = [&](int32_t r) { return r >= 0 ? uint32_t(r) < d->n_nodes : uint32_t(~r) < d->n_tris; };
         if (!refOk(d->root_ref)) {
@@ -2472,6 +2473,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
         // its depth, and a node reached twice (a cycle, or a shared subtree that could hide one)
         // would let a walk run on forever or past its stack.
         std::vector<uint8_t> seen(d->n_nodes, 0);
+        std::vector<uint32_t> parentOf(d->n_nodes, 0);
         std::vector<std::pair<int32_t, int>> todo; // (inner node, its depth)
         if (d->root_ref >= 0)
             todo.push_back({ d->root_ref, 1 });
@@ -2485,9 +2487,25 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
             }
             seen[size_t(node)] = 1;
             walkedLevels = std::max(walkedLevels, depth + 1);
+            {
+                // do this node's child boxes lie within the box its parent holds for it?
+                const float* lo = node == d->root_ref ? d->root_lo : nullptr;
+                const float* hi = node == d->root_ref ? d->root_hi : nullptr;
+                if (!lo) {
+                    const rtx_node& up = d->nodes[parentOf[size_t(node)]];
+                    const bool second = up.ref1 == node;
+                    lo = second ? up.lo1 : up.lo0;
+                    hi = second ? up.hi1 : up.hi0;
+                }
+                const rtx_node& nd = d->nodes[node];
+                for (int a = 0; a < 3; a++)
+                    boxesNested = boxesNested && nd.lo0[a] >= lo[a] && nd.lo1[a] >= lo[a] && nd.hi0[a] <= hi[a] && nd.hi1[a] <= hi[a];
+            }
             for (const int32_t child : { d->nodes[node].ref0, d->nodes[node].ref1 })
-                if (child >= 0)
+                if (child >= 0) {
+                    parentOf[size_t(child)] = uint32_t(node);
                     todo.push_back({ child, depth + 1 });
+                }
         }
     }
     for (uint32_t i = 0; i < d->n_tris; i++) {
@@ -2625,7 +2643,36 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
         std::memcpy(records.data(), packedNodes.data(), size_t(d->n_nodes) * sizeof(rtx_node));
     if (d->n_tris)
         std::memcpy(records.data() + d->n_nodes, packedTris.data(), size_t(d->n_tris) * sizeof(rtx_tri));
+    // the records of the wave-shared walk (see traverseBvhWave)
+    std::vector<float> waveNodes(size_t(d->n_nodes) * 32, 0.f), waveTris(size_t(d->n_tris) * 24, 0.f);
+    for (uint32_t i = 0; i < d->n_nodes; i++) {
+        const rtx_node& a = d->nodes[i];
+        float* o = &waveNodes[size_t(i) * 32];
+        for (int ax = 0; ax < 3; ax++) {
+            float* q = o + 8 * ax;
+            q[0] = a.lo0[ax], q[1] = a.lo1[ax], q[2] = a.hi0[ax], q[3] = a.hi1[ax];
+            q[4] = -a.hi0[ax], q[5] = -a.hi1[ax], q[6] = -a.lo0[ax], q[7] = -a.lo1[ax];
+        }
+        std::memcpy(o + 24, reinterpret_cast<const float*>(&packedNodes[i]) + 12, 8); // the device's child references
+    }
+    for (uint32_t i = 0; i < d->n_tris; i++) {
+        const rtx_tri& a = d->tris[i];
+        float* o = &waveTris[size_t(i) * 24];
+        o[0] = a.n[0], o[1] = a.n[1], o[2] = a.n[2], o[3] = a.d;
+        for (int ax = 0; ax < 3; ax++) {
+            o[4 + ax] = a.v0[ax];
+            o[8 + ax] = a.v1[ax];
+            // single IEEE subtractions, exactly the ones the triangle test makes per ray
+            o[12 + ax] = a.v2[ax] - a.v0[ax];
+            o[16 + ax] = a.v2[ax] - a.v1[ax];
+            o[20 + ax] = a.v1[ax] - a.v0[ax];
+        }
+        std::memcpy(o + 7, reinterpret_cast<const float*>(&packedTris[i]) + 13, 4); // id word, top bit = last of its leaf
+    }
+    const float *dWaveNodes = nullptr, *dWaveTris = nullptr;
     int rc = upload(s, records.data(), records.size(), &nodes);
+    rc = rc ? rc : upload(s, waveNodes.data(), waveNodes.size(), &dWaveNodes);
+    rc = rc ? rc : upload(s, waveTris.data(), waveTris.size(), &dWaveTris);
     tris = reinterpret_cast<const rtx_tri*>(nodes ? nodes + d->n_nodes : nullptr);
     rc = rc ? rc : upload(s, d->tri_attrs, d->n_tris, &attrs);
     rc = rc ? rc : upload(s, idOrder.data(), idOrder.size(), &s->d.idOrder);
@@ -2644,6 +2691,9 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     s->d.nodes = reinterpret_cast<const float4*>(nodes);
     s->d.tris = reinterpret_cast<const float4*>(tris);
     s->d.attrs = reinterpret_cast<const float4*>(attrs);
+    s->d.boxesNested = boxesNested ? 1 : 0;
+    s->d.waveNodes = reinterpret_cast<const float4*>(dWaveNodes);
+    s->d.waveTris = reinterpret_cast<const float4*>(dWaveTris);
     s->d.env = d->envmap;
     s->d.nNodes = int32_t(d->n_nodes);
     s->d.nTris = int32_t(d->n_tris);
