@@ -59,12 +59,19 @@ struct DScene {
     const float4* nodes;     // 4 x float4 per rtx_node; the array's start
     const float4* tris;      // 4 x float4 per rtx_tri (leaf order) = nodes + 4 * nNodes
     int32_t nNodes;
-    // The same tree for the wave-shared walk (traverseBvhWave), read through the scalar cache:
-    // per inner node 8 x float4 = per axis (lo0, lo1, hi0, hi1) and its mirror image
-    // (-hi0, -hi1, -lo0, -lo1), then the two child references; per triangle (leaf order)
-    // 6 x float4 = (n, D), (v0, id word), (v1, -), v2 - v0, v2 - v1, v1 - v0.
+    // The tree of the wave-shared walk (traverseBvhWave), read through the scalar cache: the
+    // binary tree with every inner node merged with its inner children, i.e. up to four
+    // boxes per node, in eight copies, one per direction octant.  Octant c's copy holds the
+    // boxes in that octant's mirror image (see traverseBvhWave) with each node's children
+    // sorted nearest first for its rays: 8 x float4 per node = lo.x of the four children,
+    // hi.x, lo.y, hi.y, lo.z, hi.z, the four child references (>= 0: node, < 0: ~first
+    // triangle of a leaf; an unused slot has an empty box), one spare.  Copy c starts at
+    // node c * nWaveNodes.  Triangles (leaf order): 6 x float4 = (n, D), (v0, id word),
+    // (v1, -), v2 - v0, v2 - v1, v1 - v0.
     const float4* waveNodes;
     const float4* waveTris;
+    int32_t nWaveNodes;
+    int32_t waveRoot;        // 0 (the root node), ~first triangle when the root is a leaf
     int32_t boxesNested;     // every child box lies within its parent's box, the root's children within the root box
     const float4* attrs;     // 4 x float4 per rtx_tri_attr
     const int32_t* idOrder;  // leaf-order record index of triangle id i (brute-force path)
@@ -314,8 +321,17 @@ RTX_DEV TriRec loadTri(const DScene& sc, int k)
 template <int STACK>
 struct LaneStack {
     int32_t* refs;  // [STACK][kBlock]
-    float* keys;    // [STACK][kBlock]
+    float* keys;    // [STACK][kBlock], directly behind refs: the wave-shared walk uses the two as ONE array of 2 * STACK keys per lane
     int tid;
+    int32_t* waveRefs; // [2 * STACK] of this wave: the wave-shared walk's subtree references (the same for every lane)
+    // the wave-shared walk's entries: a key per lane, one reference per wave
+    RTX_DEV void pushWave(int sp, int32_t ref, float key)
+    {
+        reinterpret_cast<float*>(refs)[sp * kBlock + tid] = key;
+        waveRefs[sp] = ref;
+    }
+    RTX_DEV float waveKey(int sp) const { return reinterpret_cast<const float*>(refs)[sp * kBlock + tid]; }
+    RTX_DEV int32_t waveRef(int sp) const { return __builtin_amdgcn_readfirstlane(waveRefs[sp]); }
     RTX_DEV void push(int sp, int32_t ref, float key)
     {
         refs[sp * kBlock + tid] = ref;
@@ -480,15 +496,19 @@ constexpr int kWaveNodeQuads = 8, kWaveTriQuads = 6;
 //   BOX_OUTSIDE   the same for rays that start outside the root box, hence outside every box of
 //                 a tree whose boxes are nested (checked at upload): "origin inside the box" is
 //                 false throughout and is not evaluated
-//   BOX_LITERAL   the comparison-by-comparison slab test on the unmirrored planes, for rays with
-//                 an infinite reciprocal direction component (0 * inf = NaN must fall through
-//                 the comparisons exactly as in the reference); any mix of octants
+//   BOX_LITERAL   the comparison-by-comparison slab test on the unmirrored planes (octant 0's
+//                 copy), for rays with an infinite reciprocal direction component (0 * inf =
+//                 NaN must fall through the comparisons exactly as in the reference)
 enum BoxMode { BOX_MIRRORED = 0, BOX_OUTSIDE = 1, BOX_LITERAL = 2 };
 
-// childTestFinite for one child in the mirrored frame: lo <= hi per axis and im > 0, so
-// t0 = (lo - o) * im <= t1 = (hi - o) * im already.
+// The visit rule of one child as ONE number: the key the reference would enter the child
+// with (0 when the origin lies inside, else the slab test's entry distance), or +inf when
+// its slab test misses.  The lane then enters iff !(limit < key), which is the reference's
+// `hit && !(ray.t < first)`; and a key of +inf keeps a lane out for good.
+// Mirrored frame: lo <= hi per axis and im > 0, so t0 = (lo - o) * im <= t1 = (hi - o) * im
+// already (childTestFinite's numbers without the per-axis ordering).
 template <int MODE>
-RTX_DEV void childTestMirrored(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im, float tmax, bool& h, float& key)
+RTX_DEV float childKeyMirrored(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im)
 {
     const float dlx = lox - om.x, dly = loy - om.y, dlz = loz - om.z;
     const float dhx = hix - om.x, dhy = hiy - om.y, dhz = hiz - om.z;
@@ -499,14 +519,22 @@ RTX_DEV void childTestMirrored(float lox, float loy, float loz, float hix, float
     const bool miss = first > second;
     if (first <= 0.0f)
         first = second;
-    if (MODE == BOX_OUTSIDE) {
-        key = first;
-        h = !miss && !(tmax < first);
-    } else {
+    float key = miss ? __builtin_inff() : first;
+    if (MODE != BOX_OUTSIDE) {
         const bool in = fmaxf(fmaxf(dlx, dly), dlz) <= 0.0f && fminf(fminf(dhx, dhy), dhz) >= 0.0f;
-        key = in ? 0.0f : first;
-        h = in || (!miss && !(tmax < first));
+        key = in ? 0.0f : key;
     }
+    return key;
+}
+template <int MODE>
+RTX_DEV float childKey(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im, float limit)
+{
+    if (MODE == BOX_LITERAL) {
+        float key;
+        const bool h = childTest(mk(lox, loy, loz), mk(hix, hiy, hiz), om, im, limit, key);
+        return h ? key : __builtin_inff();
+    }
+    return childKeyMirrored<MODE>(lox, loy, loz, hix, hiy, hiz, om, im);
 }
 
 // `alive`: the lanes of this call (passed the root box; for the mirrored modes: same octant,
@@ -518,52 +546,52 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
     const bool nx = MODE != BOX_LITERAL && (oct & 1u) != 0, ny = MODE != BOX_LITERAL && (oct & 2u) != 0, nz = MODE != BOX_LITERAL && (oct & 4u) != 0; // wave-uniform
     const V3 om = mk(nx ? -o.x : o.x, ny ? -o.y : o.y, nz ? -o.z : o.z);
     const V3 im = MODE == BOX_LITERAL ? inv : mk(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z));
-    const UniformF4* const nodes = uniformRecords(sc.waveNodes);
+    const UniformF4* const nodes = uniformRecords(sc.waveNodes) + size_t(MODE == BOX_LITERAL ? 0u : oct) * size_t(uint32_t(sc.nWaveNodes)) * kWaveNodeQuads;
     const UniformF4* const tris = uniformRecords(sc.waveTris);
-    const int qx = nx ? 1 : 0, qy = ny ? 3 : 2, qz = nz ? 5 : 4;
+    const float inf = __builtin_inff();
     int sp = 0;
-    int32_t cur = __builtin_amdgcn_readfirstlane(sc.rootRef);
+    int32_t cur = __builtin_amdgcn_readfirstlane(sc.waveRoot);
     bool act = alive;
     if (!anyLane(act))
         return;
     for (;;) {
         if (cur >= 0) {
             const UniformF4* p = nodes + size_t(uint32_t(cur)) * kWaveNodeQuads;
-            const NF4 X = p[qx], Y = p[qy], Z = p[qz], R = p[6];
-            bool h0, h1;
-            float k0, k1;
+            const NF4 XL = p[0], XH = p[1], YL = p[2], YH = p[3], ZL = p[4], ZH = p[5], R = p[6];
+            const float limit = act ? t : -inf; // (a lane that sits this subtree out enters nothing)
+            const float k0 = childKey<MODE>(XL.x, YL.x, ZL.x, XH.x, YH.x, ZH.x, om, im, limit);
+            const float k1 = childKey<MODE>(XL.y, YL.y, ZL.y, XH.y, YH.y, ZH.y, om, im, limit);
+            float k2 = childKey<MODE>(XL.z, YL.z, ZL.z, XH.z, YH.z, ZH.z, om, im, limit);
+            float k3 = childKey<MODE>(XL.w, YL.w, ZL.w, XH.w, YH.w, ZH.w, om, im, limit);
             if (MODE == BOX_LITERAL) {
-                h0 = childTest(mk(X.x, Y.x, Z.x), mk(X.z, Y.z, Z.z), o, inv, t, k0);
-                h1 = childTest(mk(X.y, Y.y, Z.y), mk(X.w, Y.w, Z.w), o, inv, t, k1);
-            } else {
-                childTestMirrored<MODE>(X.x, Y.x, Z.x, X.z, Y.z, Z.z, om, im, t, h0, k0);
-                childTestMirrored<MODE>(X.y, Y.y, Z.y, X.w, Y.w, Z.w, om, im, t, h1, k1);
+                // (the literal slab test orders each axis' two planes itself, so the inverted
+                // planes of an unused slot would read as all of space: go by the child count)
+                const int nChildren = __float_as_int(p[7].x);
+                k2 = nChildren > 2 ? k2 : inf;
+                k3 = nChildren > 3 ? k3 : inf;
             }
             if (COUNT)
-                tc.boxTests += act ? 2u : 0u;
-            h0 = h0 && act;
-            h1 = h1 && act;
-            const uint64_t b0 = laneMask(h0), b1 = laneMask(h1);
-            const int32_t r0 = __builtin_amdgcn_readfirstlane(__float_as_int(R.x)), r1 = __builtin_amdgcn_readfirstlane(__float_as_int(R.y));
-            if (b0 && b1) {
-                // nearer child first, by the vote of the lanes that enter any: a lane votes for
-                // child 1 if that is the only one it enters, or the nearer of its two
-                const uint64_t for1 = laneMask(h1 && (!h0 || k1 < k0));
-                const bool firstIs1 = 2 * __popcll(for1) > __popcll(b0 | b1);
-                const float inf = __builtin_inff();
-                st.push(sp++, firstIs1 ? r0 : r1, firstIs1 ? (h0 ? k0 : inf) : (h1 ? k1 : inf)); // (an infinite key: not this lane's subtree)
-                cur = firstIs1 ? r1 : r0;
-                act = firstIs1 ? h1 : h0;
-                continue;
-            }
-            if (b0 | b1) {
-                cur = b0 ? r0 : r1;
-                act = b0 ? h0 : h1;
+                tc.boxTests += act ? 4u : 0u;
+            const bool h0 = !(limit < k0), h1 = !(limit < k1), h2 = !(limit < k2), h3 = !(limit < k3);
+            const uint64_t b0 = laneMask(h0), b1 = laneMask(h1), b2 = laneMask(h2), b3 = laneMask(h3);
+            // The children are stored nearest first for this octant: the walk goes on in the
+            // first one any lane enters and keeps the others, farthest first, for later.
+            const int first = b0 ? 0 : b1 ? 1 : b2 ? 2 : b3 ? 3 : 4;
+            if (first < 4) {
+                const int32_t r0 = __float_as_int(R.x), r1 = __float_as_int(R.y), r2 = __float_as_int(R.z), r3 = __float_as_int(R.w);
+                if (b3 && first < 3)
+                    st.pushWave(sp++, r3, h3 ? k3 : inf); // (an infinite key: not this lane's subtree)
+                if (b2 && first < 2)
+                    st.pushWave(sp++, r2, h2 ? k2 : inf);
+                if (b1 && first < 1)
+                    st.pushWave(sp++, r1, h1 ? k1 : inf);
+                cur = first == 0 ? r0 : first == 1 ? r1 : first == 2 ? r2 : r3;
+                act = first == 0 ? h0 : first == 1 ? h1 : first == 2 ? h2 : h3;
                 continue;
             }
         } else {
             // a leaf: its triangles one after the other, for the lanes that entered it
-            uint32_t k = uint32_t(~cur) - uint32_t(sc.nNodes);
+            uint32_t k = uint32_t(~cur);
             for (;;) {
                 const UniformF4* q = tris + size_t(k) * kWaveTriQuads;
                 const NF4 P = q[0], A = q[1];
@@ -600,12 +628,10 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
         }
         bool have = false;
         while (sp > 0) {
-            int32_t r;
-            float key;
-            st.pop(--sp, r, key);
+            const float key = st.waveKey(--sp);
             act = alive && !(t < key);
             if (anyLane(act)) {
-                cur = __builtin_amdgcn_readfirstlane(r);
+                cur = st.waveRef(sp);
                 have = true;
                 break;
             }

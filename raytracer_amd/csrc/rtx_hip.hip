@@ -218,9 +218,9 @@ struct TraceArgs {
 template <int STACK, bool COUNT>
 __global__ void __launch_bounds__(kBlock) traceKernel(TraceArgs A)
 {
-    __shared__ int32_t sRefs[STACK * kBlock];
-    __shared__ float sKeys[STACK * kBlock];
-    LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
+    __shared__ int32_t sStack[2 * STACK * kBlock];
+    __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
+    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + STACK * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
     LaneCounters lc;
     const int lane = threadIdx.x & 63;
     WorkCursor cursor;
@@ -1071,9 +1071,9 @@ template <int STACK, bool COUNT, int MODE>
 __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES) renderKernel(RenderArgs A)
 {
     constexpr bool FULL = MODE != 0;
-    __shared__ int32_t sRefs[STACK * kBlock];
-    __shared__ float sKeys[STACK * kBlock];
-    LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
+    __shared__ int32_t sStack[2 * STACK * kBlock];
+    __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
+    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + STACK * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
     LaneCounters lc;
     const int lane = threadIdx.x & 63;
     const int slot = lane / A.lanesPerPixel, sub = lane % A.lanesPerPixel;
@@ -1451,9 +1451,9 @@ struct ShadeArgs {
 template <int STACK, bool COUNT, bool ENVL>
 __global__ void __launch_bounds__(kBlock, RTX_FULL_WAVES) shadeKernel(ShadeArgs S)
 {
-    __shared__ int32_t sRefs[STACK * kBlock];
-    __shared__ float sKeys[STACK * kBlock];
-    LaneStack<STACK> st { sRefs, sKeys, int(threadIdx.x) };
+    __shared__ int32_t sStack[2 * STACK * kBlock];
+    __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
+    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + STACK * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
     LaneCounters lc;
     const RenderArgs& A = S.R;
     const int lane = threadIdx.x & 63;
@@ -2643,18 +2643,89 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
         std::memcpy(records.data(), packedNodes.data(), size_t(d->n_nodes) * sizeof(rtx_node));
     if (d->n_tris)
         std::memcpy(records.data() + d->n_nodes, packedTris.data(), size_t(d->n_tris) * sizeof(rtx_tri));
-    // the records of the wave-shared walk (see traverseBvhWave)
-    std::vector<float> waveNodes(size_t(d->n_nodes) * 32, 0.f), waveTris(size_t(d->n_tris) * 24, 0.f);
-    for (uint32_t i = 0; i < d->n_nodes; i++) {
-        const rtx_node& a = d->nodes[i];
-        float* o = &waveNodes[size_t(i) * 32];
-        for (int ax = 0; ax < 3; ax++) {
-            float* q = o + 8 * ax;
-            q[0] = a.lo0[ax], q[1] = a.lo1[ax], q[2] = a.hi0[ax], q[3] = a.hi1[ax];
-            q[4] = -a.hi0[ax], q[5] = -a.hi1[ax], q[6] = -a.lo0[ax], q[7] = -a.lo1[ax];
+    // The tree of the wave-shared walk (see DScene::waveNodes): every inner node merged with its
+    // inner children, in eight mirrored copies with the children sorted nearest first.
+    struct Wide {
+        int32_t ref[4];   // >= 0: binary node to be merged next, < 0: leaf reference of the flat tree; INT32_MIN: unused
+        float lo[4][3], hi[4][3];
+        int n;
+    };
+    std::vector<Wide> wide;
+    int waveStackNeed = 0;
+    if (d->root_ref >= 0) {
+        // (iterative, parents before children: a node's index is its position in `wide`)
+        std::vector<int32_t> binaryOf { d->root_ref }; // binary node each wide node is made from
+        for (size_t at = 0; at < binaryOf.size(); at++) {
+            const rtx_node& top = d->nodes[binaryOf[at]];
+            Wide w;
+            w.n = 0;
+            auto add = [&](int32_t ref, const float* lo, const float* hi) {
+                w.ref[w.n] = ref;
+                std::memcpy(w.lo[w.n], lo, 12);
+                std::memcpy(w.hi[w.n], hi, 12);
+                w.n++;
+            };
+            for (int side = 0; side < 2; side++) {
+                const int32_t ref = side ? top.ref1 : top.ref0;
+                if (ref >= 0) {
+                    const rtx_node& mid = d->nodes[ref];
+                    add(mid.ref0, mid.lo0, mid.hi0);
+                    add(mid.ref1, mid.lo1, mid.hi1);
+                } else {
+                    add(ref, side ? top.lo1 : top.lo0, side ? top.hi1 : top.hi0);
+                }
+            }
+            for (int c = 0; c < w.n; c++)
+                if (w.ref[c] >= 0) { // an inner node: becomes a wide node of its own
+                    binaryOf.push_back(w.ref[c]);
+                    w.ref[c] = int32_t(binaryOf.size() - 1);
+                } // (a leaf keeps its reference: ~first triangle in leaf order)
+            wide.push_back(w);
         }
-        std::memcpy(o + 24, reinterpret_cast<const float*>(&packedNodes[i]) + 12, 8); // the device's child references
+        // entries the walk's stack can hold at once: all siblings of every node on a path
+        std::vector<int> need(wide.size(), 0);
+        for (size_t i = wide.size(); i-- > 0;) {
+            int below = 0;
+            for (int c = 0; c < wide[i].n; c++)
+                if (wide[i].ref[c] >= 0)
+                    below = std::max(below, need[size_t(wide[i].ref[c])]);
+            need[i] = wide[i].n - 1 + below;
+        }
+        waveStackNeed = need[0];
     }
+    const size_t nWide = wide.size();
+    std::vector<float> waveNodes(nWide * 8 * 32, 0.f), waveTris(size_t(d->n_tris) * 24, 0.f);
+    for (uint32_t oct = 0; oct < 8; oct++)
+        for (size_t i = 0; i < nWide; i++) {
+            const Wide& w = wide[i];
+            // this octant's mirror image of the boxes, and the children nearest first: by the
+            // mirrored box centre along the diagonal every mirrored direction has a positive
+            // share of (any order gives the same hits; a good one finds them sooner)
+            float lo[4][3], hi[4][3], along[4];
+            int order[4] = { 0, 1, 2, 3 };
+            for (int c = 0; c < w.n; c++) {
+                along[c] = 0.f;
+                for (int a = 0; a < 3; a++) {
+                    const bool neg = (oct >> a) & 1u;
+                    lo[c][a] = neg ? -w.hi[c][a] : w.lo[c][a];
+                    hi[c][a] = neg ? -w.lo[c][a] : w.hi[c][a];
+                    along[c] += lo[c][a] + hi[c][a];
+                }
+            }
+            std::stable_sort(order, order + w.n, [&](int x, int y) { return along[x] < along[y]; });
+            float* o = &waveNodes[(size_t(oct) * nWide + i) * 32];
+            for (int slot = 0; slot < 4; slot++) {
+                const bool used = slot < w.n;
+                const int c = used ? order[slot] : 0;
+                for (int a = 0; a < 3; a++) {
+                    o[8 * a + slot] = used ? lo[c][a] : INFINITY;       // (an unused slot: the empty box, entered by no ray)
+                    o[8 * a + 4 + slot] = used ? hi[c][a] : -INFINITY;
+                }
+                const int32_t ref = used ? w.ref[c] : INT32_MIN;
+                std::memcpy(o + 24 + slot, &ref, 4);
+            }
+            std::memcpy(o + 28, &w.n, 4); // number of children
+        }
     for (uint32_t i = 0; i < d->n_tris; i++) {
         const rtx_tri& a = d->tris[i];
         float* o = &waveTris[size_t(i) * 24];
@@ -2668,6 +2739,11 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
             o[20 + ax] = a.v1[ax] - a.v0[ax];
         }
         std::memcpy(o + 7, reinterpret_cast<const float*>(&packedTris[i]) + 13, 4); // id word, top bit = last of its leaf
+    }
+    if (waveStackNeed > 2 * pickStack(std::max(d->num_levels, walkedLevels)) && pickStack(std::max(d->num_levels, walkedLevels)) > 0) {
+        setErr("rtx_scene_create: the merged tree needs %d stack entries, more than its %d levels allow for", waveStackNeed, std::max(d->num_levels, walkedLevels));
+        delete s;
+        return nullptr;
     }
     const float *dWaveNodes = nullptr, *dWaveTris = nullptr;
     int rc = upload(s, records.data(), records.size(), &nodes);
@@ -2692,6 +2768,8 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     s->d.tris = reinterpret_cast<const float4*>(tris);
     s->d.attrs = reinterpret_cast<const float4*>(attrs);
     s->d.boxesNested = boxesNested ? 1 : 0;
+    s->d.nWaveNodes = int32_t(nWide);
+    s->d.waveRoot = d->root_ref >= 0 ? 0 : (emptyTree ? kEmptyRoot : ~int32_t(uint32_t(~d->root_ref)));
     s->d.waveNodes = reinterpret_cast<const float4*>(dWaveNodes);
     s->d.waveTris = reinterpret_cast<const float4*>(dWaveTris);
     s->d.env = d->envmap;
