@@ -586,7 +586,7 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                 if (b1 && first < 1)
                     st.pushWave(sp++, r1, h1 ? k1 : inf);
                 cur = first == 0 ? r0 : first == 1 ? r1 : first == 2 ? r2 : r3;
-                act = first == 0 ? h0 : first == 1 ? h1 : first == 2 ? h2 : h3;
+                act = !(limit < (first == 0 ? k0 : first == 1 ? k1 : first == 2 ? k2 : k3));
                 continue;
             }
         } else {

@@ -1026,6 +1026,8 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
     any = intersectSceneWave<STACK, COUNT>(sc, st, f, active, o, d, t, hit, lc.tc);
     const bool shade = any && f.enable_shading;
     lc.countShaded(shade);
+    if (!anyLane(any))
+        return result; // no camera ray of the wave hit anything: every sample is black, no light needs a look
     V3 hp = mk(0, 0, 0), hitN = mk(0, 0, 0), albedo = mk(0, 0, 0), ks = mk(0, 0, 0), visN = mk(0, 0, 0);
     float shin = 1.f;
     if (any) {
@@ -1217,6 +1219,10 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
             const V3 c = FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
+            } else if (!anyLane(!(c.x == 0.f && c.y == 0.f && c.z == 0.f))) {
+                // every sample of the wave is black: adding zeros in order leaves each pixel's
+                // sum where it was (+0 at the start, src/render.cpp:168), so the chain is skipped
+                accum = carry;
             } else {
                 // The reference adds the samples of a pixel one after another, in sample
                 // order, onto a zero (src/render.cpp:168-178).  The samples sit in
