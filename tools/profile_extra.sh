@@ -4,7 +4,7 @@ set -u
 OUT=$1; shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-every-block $*"
 pass() {
   name=$1; shift
   timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$OUT/$name.log"; exit 1; }
