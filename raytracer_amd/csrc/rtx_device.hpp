@@ -507,13 +507,22 @@ enum BoxMode { BOX_MIRRORED = 0, BOX_OUTSIDE = 1, BOX_LITERAL = 2 };
 // `hit && !(ray.t < first)`; and a key of +inf keeps a lane out for good.
 // Mirrored frame: lo <= hi per axis and im > 0, so t0 = (lo - o) * im <= t1 = (hi - o) * im
 // already (childTestFinite's numbers without the per-axis ordering).
-template <int MODE>
+// With ANYSIGN the lanes' directions need not share the frame's octant: a lane whose direction
+// differs from it in some axis has a negative im there (the frame's mirroring applied to its own
+// 1/d, an exact negation), and each axis' two products are put in order with min / max, which is
+// childTestFinite's arithmetic on the very same numbers.
+template <int MODE, bool ANYSIGN>
 RTX_DEV float childKeyMirrored(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im)
 {
     const float dlx = lox - om.x, dly = loy - om.y, dlz = loz - om.z;
     const float dhx = hix - om.x, dhy = hiy - om.y, dhz = hiz - om.z;
-    const float t0x = dlx * im.x, t0y = dly * im.y, t0z = dlz * im.z;
-    const float t1x = dhx * im.x, t1y = dhy * im.y, t1z = dhz * im.z;
+    float t0x = dlx * im.x, t0y = dly * im.y, t0z = dlz * im.z;
+    float t1x = dhx * im.x, t1y = dhy * im.y, t1z = dhz * im.z;
+    if (ANYSIGN) {
+        const float ax = fminf(t0x, t1x), ay = fminf(t0y, t1y), az = fminf(t0z, t1z);
+        t1x = fmaxf(t0x, t1x), t1y = fmaxf(t0y, t1y), t1z = fmaxf(t0z, t1z);
+        t0x = ax, t0y = ay, t0z = az;
+    }
     float first = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
     const float second = fminf(fminf(t1x, t1y), t1z);
     const bool miss = first > second;
@@ -526,7 +535,7 @@ RTX_DEV float childKeyMirrored(float lox, float loy, float loz, float hix, float
     }
     return key;
 }
-template <int MODE>
+template <int MODE, bool ANYSIGN>
 RTX_DEV float childKey(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im, float limit)
 {
     if (MODE == BOX_LITERAL) {
@@ -534,18 +543,18 @@ RTX_DEV float childKey(float lox, float loy, float loz, float hix, float hiy, fl
         const bool h = childTest(mk(lox, loy, loz), mk(hix, hiy, hiz), om, im, limit, key);
         return h ? key : __builtin_inff();
     }
-    return childKeyMirrored<MODE>(lox, loy, loz, hix, hiy, hiz, om, im);
+    return childKeyMirrored<MODE, ANYSIGN>(lox, loy, loz, hix, hiy, hiz, om, im);
 }
 
 // `alive`: the lanes of this call (passed the root box; for the mirrored modes: same octant,
 // finite 1/d).  t and bestK as in traverseBvh; with EARLY a lane stops taking part once it
 // knows a hit below tStop.
-template <int STACK, bool COUNT, bool EARLY, int MODE>
+template <int STACK, bool COUNT, bool EARLY, int MODE, bool ANYSIGN = false>
 RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, V3 inv, bool alive, uint32_t oct, float& t, int& bestK, TraceCounters& tc, float tStop)
 {
     const bool nx = MODE != BOX_LITERAL && (oct & 1u) != 0, ny = MODE != BOX_LITERAL && (oct & 2u) != 0, nz = MODE != BOX_LITERAL && (oct & 4u) != 0; // wave-uniform
     const V3 om = mk(nx ? -o.x : o.x, ny ? -o.y : o.y, nz ? -o.z : o.z);
-    const V3 im = MODE == BOX_LITERAL ? inv : mk(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z));
+    const V3 im = MODE == BOX_LITERAL ? inv : ANYSIGN ? mk(nx ? -inv.x : inv.x, ny ? -inv.y : inv.y, nz ? -inv.z : inv.z) : mk(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z));
     const UniformF4* const nodes = uniformRecords(sc.waveNodes) + size_t(MODE == BOX_LITERAL ? 0u : oct) * size_t(uint32_t(sc.nWaveNodes)) * kWaveNodeQuads;
     const UniformF4* const tris = uniformRecords(sc.waveTris);
     const float inf = __builtin_inff();
@@ -559,13 +568,13 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
             const UniformF4* p = nodes + size_t(uint32_t(cur)) * kWaveNodeQuads;
             const NF4 XL = p[0], XH = p[1], YL = p[2], YH = p[3], ZL = p[4], ZH = p[5], R = p[6];
             const float limit = act ? t : -inf; // (a lane that sits this subtree out enters nothing)
-            const float k0 = childKey<MODE>(XL.x, YL.x, ZL.x, XH.x, YH.x, ZH.x, om, im, limit);
-            const float k1 = childKey<MODE>(XL.y, YL.y, ZL.y, XH.y, YH.y, ZH.y, om, im, limit);
-            float k2 = childKey<MODE>(XL.z, YL.z, ZL.z, XH.z, YH.z, ZH.z, om, im, limit);
-            float k3 = childKey<MODE>(XL.w, YL.w, ZL.w, XH.w, YH.w, ZH.w, om, im, limit);
-            if (MODE == BOX_LITERAL) {
-                // (the literal slab test orders each axis' two planes itself, so the inverted
-                // planes of an unused slot would read as all of space: go by the child count)
+            const float k0 = childKey<MODE, ANYSIGN>(XL.x, YL.x, ZL.x, XH.x, YH.x, ZH.x, om, im, limit);
+            const float k1 = childKey<MODE, ANYSIGN>(XL.y, YL.y, ZL.y, XH.y, YH.y, ZH.y, om, im, limit);
+            float k2 = childKey<MODE, ANYSIGN>(XL.z, YL.z, ZL.z, XH.z, YH.z, ZH.z, om, im, limit);
+            float k3 = childKey<MODE, ANYSIGN>(XL.w, YL.w, ZL.w, XH.w, YH.w, ZH.w, om, im, limit);
+            if (MODE == BOX_LITERAL || ANYSIGN) {
+                // (a test that orders each axis' two planes itself reads the inverted planes of
+                // an unused slot as all of space: go by the child count)
                 const int nChildren = __float_as_int(p[7].x);
                 k2 = nChildren > 2 ? k2 : inf;
                 k3 = nChildren > 3 ? k3 : inf;
@@ -645,7 +654,7 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
 // pass per direction octant present among them, and one for the rays whose reciprocal
 // direction is not finite (axis-parallel rays).  t, bestK, tStop, rootLimit as in
 // traverseBvh.  Must be called by all lanes of the wave together.
-template <int STACK, bool COUNT, bool EARLY>
+template <int STACK, bool COUNT, bool EARLY, bool SPREAD = false>
 RTX_DEV void traverseWaveTogether(const DScene& sc, LaneStack<STACK>& st, bool lane, V3 o, V3 d, float& t, int& bestK, TraceCounters& tc, float tStop = 0.f, float rootLimit = 0.f)
 {
     bestK = -1;
@@ -665,6 +674,22 @@ RTX_DEV void traverseWaveTogether(const DScene& sc, LaneStack<STACK>& st, bool l
     const bool outside = sc.boxesNested && !inBox(mk(sc.rootLo), mk(sc.rootHi), o);
     const uint32_t myOct = (inv.x < 0.f ? 1u : 0u) | (inv.y < 0.f ? 2u : 0u) | (inv.z < 0.f ? 4u : 0u);
     uint64_t rest = laneMask(in && finiteInv);
+    if (SPREAD && rest) {
+        // Rays that converge on a point or leave one in a narrow bundle (the samples of an area
+        // light) can straddle a sign change of a direction component while still running side
+        // by side: they are walked in ONE pass, in the frame most of them share per axis.
+        const uint32_t total = uint32_t(__popcll(rest));
+        const uint32_t oct = (2u * uint32_t(__popcll(laneMask(in && finiteInv && inv.x < 0.f))) > total ? 1u : 0u)
+            | (2u * uint32_t(__popcll(laneMask(in && finiteInv && inv.y < 0.f))) > total ? 2u : 0u)
+            | (2u * uint32_t(__popcll(laneMask(in && finiteInv && inv.z < 0.f))) > total ? 4u : 0u);
+        if (laneMask(in && finiteInv && myOct != oct)) {
+            if (!anyLane(in && finiteInv && !outside))
+                traverseBvhWave<STACK, COUNT, EARLY, BOX_OUTSIDE, true>(sc, st, o, d, inv, in && finiteInv, oct, t, bestK, tc, tStop);
+            else
+                traverseBvhWave<STACK, COUNT, EARLY, BOX_MIRRORED, true>(sc, st, o, d, inv, in && finiteInv, oct, t, bestK, tc, tStop);
+            rest = 0;
+        }
+    }
     while (rest) {
         const uint32_t oct = uint32_t(__builtin_amdgcn_readlane(int(myOct), __builtin_ctzll(rest)));
         const bool mine = in && finiteInv && myOct == oct;
@@ -825,7 +850,7 @@ RTX_DEV bool intersectScene(const DScene& sc, LaneStack<STACK>& st, const rtx_fe
 
 // closestHit / lightVisibility / intersectScene for a whole wave at once (`lane`: this lane
 // has a query), with the triangles found by the wave-shared walk.  Same results per lane.
-template <int STACK, bool COUNT, bool EARLY = false>
+template <int STACK, bool COUNT, bool EARLY = false, bool SPREAD = false>
 RTX_DEV bool closestHitWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 o, V3 d, float& t, int& bestK, int& sphere, V3& sphereN, TraceCounters& tc, float tStop = 0.f, float clip = 0.f)
 {
     sphere = -1;
@@ -843,12 +868,12 @@ RTX_DEV bool closestHitWave(const DScene& sc, LaneStack<STACK>& st, const rtx_fe
     if (EARLY)
         t = (clip < t) ? clip : t;
     if (f.enable_accel_structure)
-        traverseWaveTogether<STACK, COUNT, EARLY>(sc, st, lane, o, d, t, bestK, tc, tStop, afterSpheres);
+        traverseWaveTogether<STACK, COUNT, EARLY, SPREAD>(sc, st, lane, o, d, t, bestK, tc, tStop, afterSpheres);
     else if (lane)
         traverseAll<COUNT>(sc, o, d, t, bestK, tc);
     return lane && (bestK >= 0 || sphere >= 0);
 }
-template <int STACK, bool COUNT>
+template <int STACK, bool COUNT, bool SPREAD = false>
 RTX_DEV float lightVisibilityWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 pos, V3 hp, TraceCounters& tc)
 {
     const V3 sd = hp - pos;
@@ -861,7 +886,7 @@ RTX_DEV float lightVisibilityWave(const DScene& sc, LaneStack<STACK>& st, const 
     }
     int bk, sph;
     V3 sn;
-    closestHitWave<STACK, COUNT, true>(sc, st, f, lane, pos, sd, ts, bk, sph, sn, tc, tStop, clip);
+    closestHitWave<STACK, COUNT, true, SPREAD>(sc, st, f, lane, pos, sd, ts, bk, sph, sn, tc, tStop, clip);
     const V3 second = pos + ts * sd;
     return (double(distance(hp, second)) > 1e-3) ? 0.0f : 1.0f;
 }

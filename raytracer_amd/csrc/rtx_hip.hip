@@ -36,6 +36,12 @@ namespace {
 #ifndef RTX_FULL_WAVES
 #define RTX_FULL_WAVES 2
 #endif
+#ifndef RTX_WALK_WAVES
+#define RTX_WALK_WAVES 2
+#endif
+#ifndef RTX_LIGHT_WAVES
+#define RTX_LIGHT_WAVES 4
+#endif
 constexpr int kMaxDepth = 8;    // frames of the reflection recursion kept per lane
 constexpr int kMaxLayers = 16;  // transparent layers along one camera ray
 
@@ -260,6 +266,58 @@ struct FastDiv {
 };
 RTX_DEV uint32_t fastDiv(uint32_t n, FastDiv d) { return d.mul ? (__umulhi(n, d.mul) >> d.shift) : n; }
 
+// ---- deferred light sampling (frames with area lights) ------------------------------
+// Such a frame is rendered in three passes instead of one state machine per camera sample:
+//   walk     (renderKernel MODE 4) follows only the radiance rays of every camera sample (camera
+//            ray, reflection / glossy children, depth first, exactly the order of
+//            getFinalColor, src/render.cpp:16-66).  Each shaded hit becomes a ShadePoint record
+//            with the number its light draws start at, and the sample's call tree is written
+//            as a tape: MISS(value) | HIT(point) | OPEN(point, ks) ... CLOSE.
+//   lights   (lightKernel, once per light that counts) the light loop of
+//            computeLightContribution (src/light.cpp:139-189) for ALL shading points of the
+//            frame: 64 / group points per wave pass, one lane per light sample, the samples'
+//            contributions added in sample order along the lanes, one result per (point, light).
+//   resolve  (resolveKernel) replays each sample's tape: Lo = sum of its lights' results in
+//            light order, value = Lo + (sum of the children's values / count) * ks, the
+//            samples of a pixel added in sample order, the driver's normalisation.
+// The light draws are numbered along the depth-first walk (that numbering is what makes a frame
+// reproducible), so a sample's tree has to be walked in order; but only the closest-hit queries
+// decide its shape, and the light samples, the bulk of the rays, depend on nothing but their
+// shading point.  Handing them to the whole chip at once takes them out of the walk's
+// dependent chain: a pixel with a deep glossy tree (up to 781 shading points at depth 4 with
+// fans of 5) no longer holds one wave for 781 light loops one after the other.
+enum TapeOp : uint32_t { TAPE_MISS = 1, TAPE_HIT = 2, TAPE_OPEN = 3, TAPE_CLOSE = 4, TAPE_LINK = 5 };
+constexpr uint32_t kTapeChunk = 8;             // entries per chunk; the last slot links to the next chunk when the tape goes on
+constexpr uint32_t kHeadUntouched = 0xffffffffu; // heads: no sample of this rank here; 0: a black sample; else 1 + first chunk
+constexpr uint32_t kNoPoint = 0xffffffffu;
+constexpr int kPools = 64, kPoolStride = 64;   // sub-pools (a wave uses pool waveIndex % 64) and their counters' distance in words
+struct ShadePoint { // what the light loop needs of one getFinalColor call
+    float hp[3], rd[3], n[3], albedo[3], ks[3], shin;
+    uint32_t key, counter; // the sample's key and the number of its first light draw here
+    uint32_t flipped;      // the viewer-side normal of testVisibilityLightSample is -n
+    uint32_t pad;
+};
+struct TapeEntry {
+    uint32_t op, point;
+    float a[3];  // MISS: the value; HIT / OPEN: Lo before the lights (the albedo when shading is off)
+    float ks[3]; // OPEN: the factor of the children's mean
+};
+static_assert(sizeof(ShadePoint) == 80 && sizeof(TapeEntry) == 32, "record sizes");
+struct Deferred {
+    uint32_t* heads;       // per (output pixel, sample)
+    TapeEntry* tape;       // pool c: chunks [c * tapePerPool, (c + 1) * tapePerPool)
+    ShadePoint* points;    // pool c: points [c * pointsPerPool, ...)
+    float* contrib;        // 3 floats per (point, counting light)
+    uint32_t* counters;    // tape chunks of pool c at [c * kPoolStride], points at [(kPools + c) * kPoolStride], overflow flag at [2 * kPools * kPoolStride]
+    uint32_t tapePerPool, pointsPerPool;
+    uint32_t nCounting;    // lights that count under the frame's features (point lights; segment / parallelogram with soft shadows)
+    uint32_t drawsPerPoint; // keyed draws one shading point's light loop consumes
+    uint32_t fanLevels;    // > 0: glossy fans are traced side by side, their hits kept in LDS for this many levels
+    uint32_t leafFans;     // the rays of a fan that ends the recursion are finished by the lanes that traced them
+    uint32_t fansTogether; // the rays of a fan walk the tree together (closestHitWave): pays when a wave serves one or two fans at a time
+};
+__host__ __device__ inline uint32_t* deferOverflow(const Deferred& D) { return D.counters + 2 * kPools * kPoolStride; }
+
 constexpr int kMaxCutBoxes = 64;
 struct RenderArgs {
     DScene sc;
@@ -310,6 +368,10 @@ struct RenderArgs {
     // line all queue at one memory channel.  A unit shorter than costFloor ticks does
     // not report at all: the order kernel has already entered its block as cheap.
     uint32_t costStride, costFloor;
+    Deferred defer;        // MODE 4 only
+    // not NULL: the launch does nothing unless this word is non-zero (the one-kernel path standing by
+    // for a deferred frame whose pools ran over)
+    const uint32_t* runIf;
 };
 RTX_DEV uint32_t costIndex(const RenderArgs& A, uint32_t block) { return (block & 63u) * A.costStride + (block >> 6); }
 
@@ -1066,15 +1128,401 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
     return result;
 }
 
+// ---- pass 1 of a deferred frame: the walk ---------------------------------------------
+// A lane's tape writer: entries go into chunks of kTapeChunk taken from the wave's pool.
+struct TapeWriter {
+    uint32_t at = 0, left = 0; // next entry (index into the tape), free entries of the current chunk
+    uint32_t head = 0;         // what goes into heads[]: 0 while nothing was written
+    bool failed = false;       // the pool ran over: the frame falls back to the one-kernel path
+};
+RTX_DEV void tapeEmit(const Deferred& D, TapeWriter& w, uint32_t op, uint32_t point, V3 a, V3 ks)
+{
+    if (w.failed)
+        return;
+    if (w.left <= 1) {
+        const uint32_t pool = waveIndex() % kPools;
+        const uint32_t k = atomicAdd(D.counters + pool * kPoolStride, 1u);
+        if (k >= D.tapePerPool) {
+            w.failed = true;
+            atomicOr(deferOverflow(D), 1u);
+            return;
+        }
+        const uint32_t chunk = pool * D.tapePerPool + k;
+        if (w.left == 1) {
+            TapeEntry link {};
+            link.op = TAPE_LINK;
+            link.point = chunk;
+            D.tape[w.at] = link;
+        } else {
+            w.head = chunk + 1;
+        }
+        w.at = chunk * kTapeChunk;
+        w.left = kTapeChunk;
+    }
+    TapeEntry e;
+    e.op = op;
+    e.point = point;
+    e.a[0] = a.x, e.a[1] = a.y, e.a[2] = a.z;
+    e.ks[0] = ks.x, e.ks[1] = ks.y, e.ks[2] = ks.z;
+    D.tape[w.at++] = e;
+    w.left--;
+}
+
+struct WalkFrame { // one getFinalColor call whose children are being followed
+    V3 reflO, reflD, nrm;
+    float blur;
+    uint32_t rngBase;
+    int32_t child, nChildren, traced;
+};
+// Hits of the glossy fans traced ahead, in LDS: entry (level, ray) of lane l at [(level * rays + ray) * kBlock + l]
+struct FanStore {
+    float* t;
+    int32_t* k;
+    int tid, rays; // rays: the fan size
+    RTX_DEV int at(int level, int ray) const { return (level * rays + ray) * kBlock + tid; }
+};
+
+// One camera sample's radiance rays, depth first; every lane of the wave calls this together.
+// The control flow is tracePath's with the light loop taken out: a shaded hit reserves the draws
+// its light loop will make (D.drawsPerPoint) and moves on.  Glossy fans of 2..kFanMax rays are
+// traced by the wave's lanes side by side as in tracePath (D.fanLevels > 0).
+template <int STACK, bool COUNT>
+RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V3 camO, V3 camD, bool active, uint32_t rngKey, uint32_t headIndex, LaneCounters& lc)
+{
+    const DScene& sc = A.sc;
+    const rtx_features& f = A.f;
+    const Deferred& D = A.defer;
+    const int lane = lane0();
+    const bool fans = D.fanLevels > 0;
+
+    int state = active ? PS_RADIANCE : PS_DONE;
+    V3 ro = camO, rd = camD;
+    uint32_t counter = 0;
+    int level = 0, depthLeft = A.depth;
+    WalkFrame frames[kMaxDepth];
+    bool preTraced = false;
+    float preT = kFltMax;
+    int32_t preK = -1;
+    const int fanGroup = min(max(A.glossyRays, 1), kFanMax), fanPerRound = 64 / fanGroup;
+    const int fanSlot = lane / fanGroup, fanChild = lane - fanSlot * fanGroup;
+    TapeWriter tape;
+    bool shadedPending = false;
+
+    while (__any(state != PS_DONE)) {
+        const uint64_t pendingFan = fans ? __ballot(state == PS_FAN) : 0ull;
+        const bool coopFan = pendingFan != 0;
+        lc.countShaded(shadedPending);
+        shadedPending = false;
+
+        V3 qo = ro, qd = rd;
+        float t = kFltMax;
+        bool trace = false;
+        uint64_t served = 0;
+        // fan iteration: the key and the counter of the lane this lane traces for, and whether
+        // that fan's rays are the last level of the recursion
+        uint32_t workerKey = 0, workerCounter = 0;
+        bool workerLeaf = false;
+        if (coopFan) {
+            // lane = one ray of a parked lane's fan (returnGlossyRay, src/shading.cpp:67-88)
+            int mine = -1;
+            uint64_t m = pendingFan;
+            for (int slot = 0; slot < fanPerRound && m; slot++) {
+                const int p = __builtin_ctzll(m);
+                m &= m - 1;
+                served |= 1ull << p;
+                if (fanSlot == slot)
+                    mine = p;
+            }
+            const int src = mine >= 0 ? mine : 0;
+            const WalkFrame& own = frames[level > 0 ? level - 1 : 0]; // (a parked lane's fan is its innermost frame)
+            const V3 fD = laneValue(own.reflD, src), fO = laneValue(own.reflO, src), fN = laneValue(own.nrm, src);
+            const float fBlur = laneValue(own.blur, src);
+            const uint32_t fBase = uint32_t(__shfl(int(own.rngBase), src, 64)), fKey = uint32_t(__shfl(int(rngKey), src, 64));
+            const int fCount = __shfl(own.nChildren, src, 64);
+            workerKey = fKey;
+            workerCounter = uint32_t(__shfl(int(counter), src, 64));
+            // (every lane takes part in the exchange: a lane that sat it out could not be read from)
+            const int fDepthLeft = __shfl(depthLeft, src, 64);
+            workerLeaf = mine >= 0 && fDepthLeft == 0 && f.enable_shading && D.leafFans; // the fan's rays end the recursion (src/render.cpp:22)
+            if (mine >= 0 && fanChild < fCount) {
+                const V3 w = normalize(fD);
+                const V3 tt = normalize(w - mk(0.1f, 0.0f, 0.0f));
+                const V3 u = normalize(cross(tt, w));
+                const V3 v = normalize(cross(w, u));
+                const float ua = -fBlur / 2.0f + fBlur * keyedUniform(fKey, fBase + 2u * uint32_t(fanChild));
+                const float va = -fBlur / 2.0f + fBlur * keyedUniform(fKey, fBase + 2u * uint32_t(fanChild) + 1u);
+                const V3 dir = fD + (ua * u + va * v);
+                const float cosinus = dot(normalize(dir), fN);
+                const float sinus = __builtin_sqrtf(1.0f - cosinus * cosinus);
+                qo = fO;
+                qd = dir;
+                trace = cosinus > 0.0f && sinus > 0.0f; // the others are never followed (src/render.cpp:31-38)
+            }
+        } else {
+            lc.countPrimary(state == PS_RADIANCE && level == 0);
+            lc.countBounce(state == PS_RADIANCE && level != 0);
+            trace = state == PS_RADIANCE && !preTraced;
+        }
+
+        Hit hit;
+        bool any = false;
+        int bestK = -1, sphere = -1;
+        V3 sphereN = mk(0, 0, 0);
+        lc.countTraced(trace);
+        if (coopFan && D.fansTogether) // the rays of a fan leave one point in a narrow bundle
+            any = closestHitWave<STACK, COUNT, false, true>(sc, st, f, trace, qo, qd, t, bestK, sphere, sphereN, lc.tc);
+        else if (trace)
+            any = closestHit<STACK, COUNT>(sc, st, f, qo, qd, t, bestK, sphere, sphereN, lc.tc);
+        if (!coopFan && state == PS_RADIANCE && preTraced) {
+            t = preT;
+            bestK = preK;
+            any = bestK >= 0;
+            preTraced = false;
+        }
+        const bool landed = !coopFan && state == PS_RADIANCE;
+        // The rays of a fan that ends the recursion are whole getFinalColor calls by themselves
+        // (hit or miss, the lights, no children): the lanes that traced them make their shading
+        // points on the spot, all at once, and the parked lane only writes the tape.  The light
+        // draws of ray j start after those of the fan's earlier rays that hit something.
+        const bool leafHit = coopFan && workerLeaf && trace && any;
+        if (landed)
+            hitAttributes(sc, f, ro, rd, t, bestK, sphere, sphereN, hit);
+        else if (leafHit)
+            hitAttributes(sc, f, qo, qd, t, bestK, sphere, sphereN, hit);
+        lc.countBounce(coopFan && workerLeaf && trace);
+
+        // numbers for this iteration's shading points: one atomic per wave, the lanes in order
+        const bool wantsPoint = (landed || leafHit) && any && f.enable_shading && !tape.failed;
+        uint32_t point = kNoPoint;
+        {
+            const uint64_t want = __ballot(wantsPoint);
+            if (want) {
+                const uint32_t pool = waveIndex() % kPools, n = uint32_t(__popcll(want));
+                uint32_t base = 0;
+                if (lane == int(__builtin_ctzll(want)))
+                    base = atomicAdd(D.counters + (kPools + pool) * kPoolStride, n);
+                base = uint32_t(__builtin_amdgcn_readlane(int(base), int(__builtin_ctzll(want))));
+                const uint32_t mine = base + uint32_t(__popcll(want & ((1ull << lane) - 1ull)));
+                if (wantsPoint) {
+                    if (mine < D.pointsPerPool) {
+                        point = pool * D.pointsPerPool + mine;
+                    } else {
+                        tape.failed = true;
+                        atomicOr(deferOverflow(D), 1u);
+                    }
+                }
+            }
+        }
+
+        int phase = PH_NONE;
+        if (coopFan) {
+            if (anyLane(workerLeaf)) {
+                const uint64_t hits = __ballot(leafHit && f.enable_shading);
+                if (leafHit && f.enable_shading) {
+                    shadedPending = true; // (counted for the wave, whichever lane reports it)
+                    if (point != kNoPoint) {
+                        const uint64_t group = ((fanGroup < 64 ? (1ull << fanGroup) : 0ull) - 1ull) << (fanSlot * fanGroup);
+                        const uint32_t earlier = uint32_t(__popcll(hits & group & ((1ull << lane) - 1ull)));
+                        const V3 hp = qo + t * qd;
+                        const rtx_material& m = sc.mats[hit.material];
+                        const V3 albedo = albedoOf(sc, f, m, qo, qd, hit);
+                        ShadePoint P;
+                        P.hp[0] = hp.x, P.hp[1] = hp.y, P.hp[2] = hp.z;
+                        P.rd[0] = qd.x, P.rd[1] = qd.y, P.rd[2] = qd.z;
+                        P.n[0] = hit.normal.x, P.n[1] = hit.normal.y, P.n[2] = hit.normal.z;
+                        P.albedo[0] = albedo.x, P.albedo[1] = albedo.y, P.albedo[2] = albedo.z;
+                        P.ks[0] = m.ks[0], P.ks[1] = m.ks[1], P.ks[2] = m.ks[2];
+                        P.shin = m.shininess;
+                        P.key = workerKey;
+                        P.counter = workerCounter + earlier * D.drawsPerPoint;
+                        P.flipped = (dot(normalize(hit.normal), normalize(qo - hp)) < -1e-6f) ? 1u : 0u;
+                        P.pad = 0;
+                        D.points[point] = P;
+                    }
+                }
+            }
+            // the k-th served lane finds ray j of its fan in lane k * fanGroup + j
+            const int k = __popcll(served & ((1ull << lane) - 1ull));
+            const bool mineServed = (served >> lane) & 1ull;
+            const int lv = level > 0 ? level - 1 : 0;
+            const bool myLeaf = mineServed && depthLeft == 0 && f.enable_shading && D.leafFans;
+            // what a ray of a last-level fan leaves on the tape: 0 not followed, 1 a miss, 2 a hit
+            const int outcome = !trace ? 0 : !any ? 1 : 2;
+            for (int j = 0; j < fanGroup; j++) {
+                const int from = min(k * fanGroup + j, 63);
+                const float jt = __shfl(t, from, 64);
+                const int jk = __shfl(bestK, from, 64);
+                const int jOutcome = __shfl(outcome, from, 64);
+                const uint32_t jPoint = uint32_t(__shfl(int(point), from, 64));
+                const int jFailed = __shfl(int(tape.failed), from, 64);
+                if (myLeaf && j < frames[lv].nChildren) {
+                    if (jFailed)
+                        tape.failed = true;
+                    if (jOutcome == 1) {
+                        tapeEmit(D, tape, TAPE_MISS, kNoPoint, mk(0, 0, 0), mk(0, 0, 0)); // (no environment map in a deferred frame)
+                    } else if (jOutcome == 2) {
+                        tapeEmit(D, tape, TAPE_HIT, jPoint, mk(0, 0, 0), mk(0, 0, 0));
+                        counter += D.drawsPerPoint;
+                    }
+                } else if (mineServed) {
+                    fan.t[fan.at(lv, j)] = jt;
+                    fan.k[fan.at(lv, j)] = jk;
+                }
+            }
+            if (myLeaf) {
+                // every child has returned
+                tapeEmit(D, tape, TAPE_CLOSE, kNoPoint, mk(0, 0, 0), mk(0, 0, 0));
+                level--;
+                depthLeft++;
+                state = PS_RADIANCE; // left again below
+                phase = PH_RETURN;
+            } else if (mineServed) {
+                frames[lv].traced = 1;
+                state = PS_RADIANCE; // left again below
+                phase = PH_NEXT_CHILD;
+            }
+        } else if (state == PS_RADIANCE) {
+            if (!any) {
+                // src/render.cpp:61-64
+                const V3 value = f.enable_environment_mapping ? envColor(sc, f, rd) : mk(0, 0, 0);
+                if (!(level == 0 && tape.head == 0 && value.x == 0.f && value.y == 0.f && value.z == 0.f)) // (a black camera sample needs no tape)
+                    tapeEmit(D, tape, TAPE_MISS, kNoPoint, value, mk(0, 0, 0));
+                phase = PH_RETURN;
+            } else {
+                const V3 hp = ro + t * rd, hitN = hit.normal;
+                const rtx_material& m = sc.mats[hit.material];
+                const V3 ks = mk(m.ks);
+                const float shin = m.shininess;
+                V3 before = mk(m.kd); // shading off: the albedo is the light contribution (src/light.cpp:184-188)
+                if (f.enable_shading) {
+                    shadedPending = true;
+                    before = mk(0, 0, 0);
+                    if (point != kNoPoint) {
+                        const V3 albedo = albedoOf(sc, f, m, ro, rd, hit);
+                        ShadePoint P;
+                        P.hp[0] = hp.x, P.hp[1] = hp.y, P.hp[2] = hp.z;
+                        P.rd[0] = rd.x, P.rd[1] = rd.y, P.rd[2] = rd.z;
+                        P.n[0] = hitN.x, P.n[1] = hitN.y, P.n[2] = hitN.z;
+                        P.albedo[0] = albedo.x, P.albedo[1] = albedo.y, P.albedo[2] = albedo.z;
+                        P.ks[0] = ks.x, P.ks[1] = ks.y, P.ks[2] = ks.z;
+                        P.shin = shin;
+                        P.key = rngKey;
+                        P.counter = counter;
+                        // testVisibilityLightSample's viewer-side normal (src/light.cpp:72-77)
+                        P.flipped = (dot(normalize(hitN), normalize(ro - hp)) < -1e-6f) ? 1u : 0u;
+                        P.pad = 0;
+                        D.points[point] = P;
+                    }
+                    counter += D.drawsPerPoint;
+                }
+                // src/render.cpp:22-52
+                const bool bounce = f.enable_recursive && depthLeft > 0 && !(ks.x == 0.f && ks.y == 0.f && ks.z == 0.f) && level < kMaxDepth;
+                if (!bounce) {
+                    tapeEmit(D, tape, TAPE_HIT, point, before, mk(0, 0, 0));
+                    phase = PH_RETURN;
+                } else {
+                    tapeEmit(D, tape, TAPE_OPEN, point, before, ks);
+                    WalkFrame& F = frames[level];
+                    F.child = 0;
+                    const V3 r = reflectDir(rd, hitN);
+                    F.reflO = (ro + rd * t) + float(1e-5) * r;
+                    F.reflD = r;
+                    F.nrm = normalize(hitN);
+                    if (f.enable_glossy_reflection) {
+                        // the whole fan is drawn before any of it is traced (src/shading.cpp:98-105)
+                        F.nChildren = A.glossyRays;
+                        F.blur = 1.0f / shin;
+                        F.rngBase = counter;
+                        counter += 2u * uint32_t(A.glossyRays);
+                    } else {
+                        F.nChildren = 1;
+                        F.blur = 0.f;
+                        F.rngBase = 0;
+                    }
+                    F.traced = 0;
+                    level++;
+                    depthLeft--;
+                    phase = PH_NEXT_CHILD;
+                    if (fans && f.enable_glossy_reflection && F.nChildren > 1 && F.nChildren <= kFanMax && level <= int(D.fanLevels)) {
+                        state = PS_FAN; // traced by the whole wave in the next iteration
+                        phase = PH_NONE;
+                    }
+                }
+            }
+        }
+        if (tape.failed && state != PS_DONE) { // the frame is rendered again by the one-kernel path: stop here
+            state = PS_DONE;
+            phase = PH_NONE;
+        }
+
+        bool launched = phase == PH_NONE;
+        while (!launched) {
+            if (phase == PH_NEXT_CHILD) {
+                WalkFrame& F = frames[level - 1];
+                phase = PH_RETURN;
+                while (F.child < F.nChildren) {
+                    const int k = F.child++;
+                    V3 dir = F.reflD;
+                    if (f.enable_glossy_reflection) {
+                        // returnGlossyRay, src/shading.cpp:67-88
+                        const V3 w = normalize(F.reflD);
+                        const V3 tt = normalize(w - mk(0.1f, 0.0f, 0.0f));
+                        const V3 u = normalize(cross(tt, w));
+                        const V3 v = normalize(cross(w, u));
+                        const float ua = -F.blur / 2.0f + F.blur * keyedUniform(rngKey, F.rngBase + 2u * uint32_t(k));
+                        const float va = -F.blur / 2.0f + F.blur * keyedUniform(rngKey, F.rngBase + 2u * uint32_t(k) + 1u);
+                        dir = F.reflD + (ua * u + va * v);
+                    }
+                    const float cosinus = dot(normalize(dir), F.nrm);
+                    const float sinus = __builtin_sqrtf(1.0f - cosinus * cosinus);
+                    if (cosinus > 0.0f && sinus > 0.0f) {
+                        ro = F.reflO;
+                        rd = dir;
+                        if (F.traced) {
+                            preTraced = true;
+                            preT = fan.t[fan.at(level - 1, k)];
+                            preK = fan.k[fan.at(level - 1, k)];
+                        }
+                        state = PS_RADIANCE;
+                        launched = true;
+                        break;
+                    }
+                }
+                if (launched)
+                    break;
+                // every child has returned: color * (1 / count), Lo + color * ks (resolveKernel)
+                tapeEmit(D, tape, TAPE_CLOSE, kNoPoint, mk(0, 0, 0), mk(0, 0, 0));
+                level--;
+                depthLeft++;
+            }
+            if (phase == PH_RETURN) {
+                if (level > 0) {
+                    phase = PH_NEXT_CHILD;
+                    continue;
+                }
+                state = PS_DONE;
+                launched = true;
+            }
+        }
+    }
+    lc.countShaded(shadedPending);
+    if (active && !tape.failed)
+        D.heads[headIndex] = tape.head;
+}
+
 // MODE 0: point lights + hard shadows only (tracePathLean); 1: the general path;
 // 2: the general path with environment light sampling; 3: the general path with
-// glossy fans traced by the wave's lanes side by side
+// glossy fans traced by the wave's lanes side by side; 4: the walk of a deferred
+// frame (walkPath: radiance rays only, no pixel is written)
 template <int STACK, bool COUNT, int MODE>
-__global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES) renderKernel(RenderArgs A)
+__global__ void __launch_bounds__(kBlock, MODE == 0 ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A)
 {
     constexpr bool FULL = MODE != 0;
     __shared__ int32_t sStack[2 * STACK * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
+    extern __shared__ int32_t sFan[]; // MODE 4: fanLevels * fan size * kBlock distances, then as many triangle records
+    if (A.runIf && __hip_atomic_load(A.runIf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        return;
     LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + STACK * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
     LaneCounters lc;
     const int lane = threadIdx.x & 63;
@@ -1216,7 +1664,13 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                     }
                 }
             }
-            const V3 c = FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT>(A, st, o, d, active, lc);
+            if (MODE == 4) {
+                const int fanRays = min(max(A.glossyRays, 1), kFanMax);
+                const FanStore fan { reinterpret_cast<float*>(sFan), sFan + A.defer.fanLevels * fanRays * kBlock, int(threadIdx.x), fanRays };
+                walkPath<STACK, COUNT>(A, st, fan, o, d, active, key, storeIndex * uint32_t(A.samples) + uint32_t(sample), lc);
+                continue; // (the pixel is written by resolveKernel)
+            }
+            const V3 c = MODE == 4 ? mk(0, 0, 0) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
             } else if (!anyLane(!(c.x == 0.f && c.y == 0.f && c.z == 0.f))) {
@@ -1260,7 +1714,7 @@ __global__ void __launch_bounds__(kBlock, MODE ? RTX_FULL_WAVES : RTX_LEAN_WAVES
                 }
             }
         }
-        if (writer && storeIndex != 0xffffffffu) {
+        if (MODE != 4 && writer && storeIndex != 0xffffffffu) {
             {
                 const uint32_t outIndex = storeIndex;
                 V3 px = accum;
@@ -1446,6 +1900,245 @@ __global__ void __launch_bounds__(256) placeBlocksKernel(const uint8_t* classes,
     });
 }
 
+// ---- passes 2 and 3 of a deferred frame -------------------------------------------------
+struct LightArgs {
+    DScene sc;
+    rtx_features f;
+    Deferred defer;
+    int32_t light;          // index into the scene's lights
+    int32_t slot;           // its place among the lights that count (index into a point's results)
+    int32_t nS;             // samples (1 for a point light)
+    uint32_t counterOffset; // keyed draws the point's earlier lights consume
+    const uint32_t* unitStart; // [kPools + 1]: first unit of each pool's points for this light (made by planLightsKernel)
+    WorkQueue work;
+    unsigned long long* stats;
+};
+// After the walk: how many units (64 / group points each) every pool's points make for a light
+// whose samples fill `group` lanes, as a running sum (unitStart), and the work queue's plan.
+// One wave.  A frame whose pools ran over gets no units at all.
+__global__ void __launch_bounds__(64) planLightsKernel(Deferred D, uint32_t group, uint32_t* unitStart, uint32_t* plan)
+{
+    const uint32_t lane = threadIdx.x;
+    const bool over = *deferOverflow(D) != 0;
+    const uint32_t count = over ? 0u : min(D.counters[(kPools + lane) * kPoolStride], D.pointsPerPool);
+    const uint32_t perUnit = 64u / group;
+    uint32_t v = (count + perUnit - 1u) / perUnit;
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t up = uint32_t(__shfl_up(int(v), o, 64));
+        v += lane >= o ? up : 0u;
+    }
+    unitStart[lane + 1] = v;
+    if (lane == 0)
+        unitStart[0] = 0;
+    if (lane == 63) {
+        plan[0] = plan[1] = plan[2] = v;
+        plan[3] = plan[4] = plan[5] = 1;
+    }
+}
+
+// The light loop's body for one light and every shading point of the frame
+// (computeLightContribution, src/light.cpp:139-189; sampleSegmentLight / sampleParallelogramLight,
+// :26-45; testVisibilityLightSample, :70-102).  A unit = 64 / group shading points of one pool,
+// group = min(samples, 64) lanes each: lane = one light sample, its shadow ray traced, the
+// contributions added in sample order along the lanes (a light with more than 64 samples takes
+// several rounds per point, the sum carried over), the mean written to the point's result.
+// A point light is a light of one sample: 64 points per unit.
+template <int STACK, bool COUNT>
+__global__ void __launch_bounds__(kBlock, RTX_LIGHT_WAVES) lightKernel(LightArgs L)
+{
+    __shared__ int32_t sStack[2 * STACK * kBlock];
+    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + STACK * kBlock), int(threadIdx.x), nullptr };
+    LaneCounters lc;
+    const DScene& sc = L.sc;
+    const Deferred& D = L.defer;
+    const int lane = threadIdx.x & 63;
+    const rtx_light& light = sc.lights[L.light];
+    const int type = __builtin_amdgcn_readfirstlane(light.type);
+    const bool isPoint = type == RTX_LIGHT_POINT;
+    const int nS = isPoint ? 1 : L.nS;
+    const int group = nS < 64 ? nS : 64, perUnit = 64 / group, rounds = (nS + 63) / 64;
+    const int mySlot = lane / group, mySample = lane - mySlot * group;
+    const bool shadowed = !isPoint || L.f.enable_hard_shadow; // (area lights always test visibility, src/light.cpp:160,173)
+    const uint32_t startOfMine = L.unitStart[lane]; // lane c: first unit of pool c
+    WorkCursor cursor;
+    openCursor(L.work, cursor);
+    uint32_t first, last;
+    while (nextChunk(L.work, cursor, first, last)) {
+        for (uint32_t unit = first; unit < last; unit++) {
+            const uint32_t pool = uint32_t(__popcll(__ballot(startOfMine <= unit))) - 1u;
+            const uint32_t inPool = (unit - uint32_t(__builtin_amdgcn_readlane(int(startOfMine), int(pool)))) * uint32_t(perUnit) + uint32_t(mySlot);
+            const uint32_t count = min(__builtin_amdgcn_readfirstlane(D.counters[(kPools + pool) * kPoolStride]), D.pointsPerPool);
+            const bool valid = mySlot < perUnit && inPool < count;
+            const uint32_t point = pool * D.pointsPerPool + (valid ? inPool : 0u);
+            V3 hp = mk(0, 0, 0), Rd = mk(0, 0, 1), N = mk(0, 0, 1), albedo = mk(0, 0, 0), ks = mk(0, 0, 0);
+            float shin = 1.f;
+            uint32_t key = 0, counter = 0;
+            bool flipped = false;
+            if (valid) {
+                const ShadePoint& P = D.points[point];
+                hp = mk(P.hp), Rd = mk(P.rd), N = mk(P.n), albedo = mk(P.albedo), ks = mk(P.ks);
+                shin = P.shin;
+                key = P.key;
+                counter = P.counter + L.counterOffset;
+                flipped = P.flipped != 0;
+            }
+            V3 carry = mk(0, 0, 0), result = mk(0, 0, 0);
+            for (int round = 0; round < rounds; round++) {
+                const int sampleIndex = round * 64 + mySample;
+                const bool worker = valid && sampleIndex < nS;
+                V3 pos = mk(light.p[0]), col = mk(light.c[0]);
+                if (type == RTX_LIGHT_SEGMENT) {
+                    // src/light.cpp:26-32
+                    const V3 e0 = mk(light.p[0]), e1 = mk(light.p[1]);
+                    const float a = keyedUniform(key, counter + uint32_t(sampleIndex));
+                    pos = a * (e1 - e0) + e0;
+                    col = (1 - a) * mk(light.c[0]) + a * mk(light.c[1]);
+                } else if (type == RTX_LIGHT_PARALLELOGRAM) {
+                    // src/light.cpp:36-45
+                    const float a1 = keyedUniform(key, counter + 2u * uint32_t(sampleIndex));
+                    const V3 c1 = (1 - a1) * mk(light.c[0]) + a1 * mk(light.c[1]);
+                    const V3 c2 = (1 - a1) * mk(light.c[2]) + a1 * mk(light.c[3]);
+                    const float a2 = keyedUniform(key, counter + 2u * uint32_t(sampleIndex) + 1u);
+                    col = (1 - a2) * c1 + a2 * c2;
+                    pos = mk(light.p[0]) + mk(light.p[1]) * a1 + mk(light.p[2]) * a2;
+                }
+                V3 c = mk(0, 0, 0);
+                if (worker)
+                    c = phong(pos, col, hp, Rd, N, albedo, ks, shin);
+                if (shadowed) {
+                    lc.countShadow(worker);
+                    const V3 visN = flipped ? -N : N;
+                    const bool facing = worker && lightFacesSurface(pos, hp, visN);
+                    lc.countTraced(facing);
+                    // (lane by lane: the samples of an area light start all over the light, a bundle
+                    // too wide to be walked through the tree together; measured 1.7x slower that way)
+                    const float visible = facing ? lightVisibility<STACK, COUNT>(sc, st, L.f, pos, hp, visN, lc.tc) : 0.0f;
+                    c = c * (facing ? visible : 0.0f);
+                }
+                if (isPoint) {
+                    result = c;
+                } else {
+                    // `avg += contribution` in sample order (src/light.cpp:160-163, 173-176)
+                    const int cnt = min(group, nS - round * 64);
+                    const bool head = mySample == 0;
+                    float rx = head ? carry.x + c.x : c.x, ry = head ? carry.y + c.y : c.y, rz = head ? carry.z + c.z : c.z;
+                    for (int j = 1; j < cnt; j++) {
+                        const float nx = fromPreviousLane(rx) + c.x, ny = fromPreviousLane(ry) + c.y, nz = fromPreviousLane(rz) + c.z;
+                        rx = head ? rx : nx;
+                        ry = head ? ry : ny;
+                        rz = head ? rz : nz;
+                    }
+                    if (round + 1 < rounds)
+                        carry = mk(fromLane(rx, cnt - 1), fromLane(ry, cnt - 1), fromLane(rz, cnt - 1)); // (one point per unit here)
+                    else
+                        result = mk(rx, ry, rz) * float(1.0 / double(float(nS))); // the sum sits in the group's last lane
+                }
+            }
+            const int lastSample = isPoint ? 0 : min(group, nS - (rounds - 1) * 64) - 1;
+            if (valid && mySample == lastSample) {
+                float* dst = D.contrib + (size_t(point) * D.nCounting + uint32_t(L.slot)) * 3;
+                dst[0] = result.x;
+                dst[1] = result.y;
+                dst[2] = result.z;
+            }
+        }
+    }
+    flushCounters<COUNT>(lc, L.stats);
+}
+
+struct ResolveArgs {
+    Deferred defer;
+    float* out;
+    uint32_t nPixels;   // output pixels (the frame, or this rank's tile buffer)
+    int32_t samples, driver;
+};
+// getFinalColor's arithmetic replayed from a sample's tape (src/render.cpp:16-66)
+RTX_DEV V3 resolveTape(const Deferred& D, uint32_t head)
+{
+    if (head == 0)
+        return mk(0, 0, 0);
+    V3 Lo[kMaxDepth], ks[kMaxDepth], acc[kMaxDepth];
+    int32_t count[kMaxDepth];
+    int level = 0;
+    uint32_t at = (head - 1) * kTapeChunk;
+    for (;;) {
+        const TapeEntry e = D.tape[at];
+        if (e.op == TAPE_LINK) {
+            at = e.point * kTapeChunk;
+            continue;
+        }
+        at++;
+        V3 value = mk(e.a);
+        if (e.op == TAPE_HIT || e.op == TAPE_OPEN) {
+            // Lo: the lights in scene order (src/light.cpp:146-181)
+            if (e.point != kNoPoint) {
+                const float* c = D.contrib + size_t(e.point) * D.nCounting * 3;
+                for (uint32_t j = 0; j < D.nCounting; j++)
+                    value = value + mk(c + 3 * j);
+            }
+            if (e.op == TAPE_OPEN) {
+                Lo[level] = value;
+                ks[level] = mk(e.ks);
+                acc[level] = mk(0, 0, 0);
+                count[level] = 0;
+                level++;
+                continue;
+            }
+        } else if (e.op == TAPE_CLOSE) {
+            // color *= 1/count (0 * inf = NaN when no child was followed), Lo + color * ks
+            level--;
+            const V3 color = acc[level] * (1.0f / float(count[level]));
+            value = Lo[level] + color * ks[level];
+        }
+        if (level == 0)
+            return value;
+        acc[level - 1] = acc[level - 1] + value;
+        count[level - 1]++;
+    }
+}
+__global__ void __launch_bounds__(256) resolveKernel(ResolveArgs R)
+{
+    const Deferred& D = R.defer;
+    if (*deferOverflow(D) != 0)
+        return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= R.nPixels)
+        return;
+    const uint32_t* heads = D.heads + size_t(i) * uint32_t(R.samples);
+    if (heads[0] == kHeadUntouched)
+        return; // another rank's pixel, or a block that cannot see the scene (written black by the walk)
+    // the samples of a pixel are added one after another onto a zero (src/render.cpp:168-178)
+    const bool averaging = R.driver == RTX_DRIVER_MRAYS || R.driver == RTX_DRIVER_DOF || R.driver == RTX_DRIVER_MOTION_BLUR;
+    V3 accum = mk(0, 0, 0);
+    for (int s = 0; averaging && s < R.samples; s++)
+        accum = accum + resolveTape(D, heads[s]);
+    V3 px = accum;
+    if (R.driver == RTX_DRIVER_MRAYS) {
+        const float inv = 1.0f / (float(R.samples) * 1.0f);
+        px = accum * mk(inv, inv, inv);
+    } else if (R.driver == RTX_DRIVER_DOF) {
+        const float inv = 1.0f / float(R.samples);
+        px = accum * mk(inv, inv, inv);
+    } else if (R.driver == RTX_DRIVER_MOTION_BLUR) {
+        px = accum / float(R.samples);
+    } else {
+        px = resolveTape(D, heads[0]); // (not a sum: the one sample as it is, -0 included)
+    }
+    float* dst = R.out + size_t(i) * 3;
+    dst[0] = px.x;
+    dst[1] = px.y;
+    dst[2] = px.z;
+}
+// A deferred frame whose pools ran over is rendered again by the one-kernel path, which counts
+// its rays itself: the walk's counts are dropped.  One wave.
+__global__ void __launch_bounds__(64) dropCountsIfOverflowKernel(Deferred D, unsigned long long* stats)
+{
+    if (*deferOverflow(D) == 0)
+        return;
+    for (uint32_t w = threadIdx.x; w < uint32_t(kStatSlots * kStatStride); w += 64u)
+        stats[w] = 0;
+}
+
 // Batch form of getFinalColor (src/render.cpp:16-66): lane = caller-supplied ray.
 struct ShadeArgs {
     RenderArgs R;          // scene, features, depth, sampling knobs, counters (frame fields unused)
@@ -1582,7 +2275,25 @@ struct DeviceCtx {
     std::mutex hostFrame;
     float* frame = nullptr;
     size_t frameBytes = 0;
+    // memory of the deferred frames (see Deferred), grown on demand and kept
+    struct DeferPools {
+        uint32_t* heads = nullptr;
+        size_t headWords = 0;
+        TapeEntry* tape = nullptr;
+        uint32_t tapePerPool = 0;
+        ShadePoint* points = nullptr;
+        float* contrib = nullptr;
+        uint32_t pointsPerPool = 0, contribLights = 0;
+        uint32_t* counters = nullptr;   // the pools' counters and the overflow flag, then the light launches' ticket counters, unit tables and plans
+        uint32_t* overflowHost = nullptr; // page-locked copy of the last deferred frame's overflow flag
+        uint32_t wantPoints = 0;        // points per pool asked for by the last frame that ran over
+    } defer;
 };
+constexpr int kMaxDeferLights = 8;
+constexpr size_t kDeferCounterWords = 2 * size_t(kPools) * kPoolStride + 64;
+constexpr size_t kDeferTicketWords = size_t(kQueues) * kQueueStride;
+constexpr size_t kDeferUnitWords = 128, kDeferPlanWords = 64;
+constexpr size_t kDeferControlWords = kDeferCounterWords + kMaxDeferLights * (kDeferTicketWords + kDeferUnitWords + kDeferPlanWords);
 
 uint64_t hostMulMod(uint64_t a, uint64_t b) { return (a * b) % 2147483647ull; }
 uint64_t hostPowMod(uint64_t base, uint64_t e)
@@ -1612,6 +2323,7 @@ struct rtx_scene {
     int numLevels = 0;
     bool hasEnv = false;
     bool hasAreaLight = false; // a segment or parallelogram light
+    std::vector<int32_t> lightTypes;
     // boxes of a shallow cut through the tree (at most kMaxCutBoxes; every triangle lies
     // in one of them), for the per-frame visibility rectangles
     std::vector<std::array<float, 6>> cutBoxes;
@@ -1654,10 +2366,10 @@ int pickStack(int numLevels)
 // Persistent grid: as many 4-wave blocks as the kernel's registers and LDS let
 // the chip hold at once.  No block waits on another, so a smaller share of the
 // chip (a busy GPU) only makes the launch slower, never stuck.
-int gridFor(const DeviceCtx* c, const void* kernel)
+int gridFor(const DeviceCtx* c, const void* kernel, size_t dynamicLds = 0)
 {
     int perCU = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, 0) != hipSuccess || perCU < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, dynamicLds) != hipSuccess || perCU < 1)
         perCU = 2;
     if (const char* e = getenv("RTX_GRID_PER_CU"))
         perCU = std::max(1, atoi(e));
@@ -1700,16 +2412,20 @@ int launchTrace(DeviceCtx* c, const TraceArgs& A, bool count)
 }
 
 template <int STACK>
-int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode)
+int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode, size_t dynamicLds = 0)
 {
 #define RTX_LAUNCH(CNT, MODEV)                                                                                    \
     {                                                                                                             \
         const void* k = (const void*)renderKernel<STACK, CNT, MODEV>;                                             \
-        const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.work.nChunks + 3) / 4)));                \
-        hipLaunchKernelGGL((renderKernel<STACK, CNT, MODEV>), dim3(grid), dim3(kBlock), 0, c->stream, A);         \
+        if (dynamicLds)                                                                                           \
+            (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(dynamicLds));            \
+        const int grid = std::max(1, std::min<int>(gridFor(c, k, dynamicLds), int((A.work.nChunks + 3) / 4)));    \
+        hipLaunchKernelGGL((renderKernel<STACK, CNT, MODEV>), dim3(grid), dim3(kBlock), dynamicLds, c->stream, A); \
     }
     if (count) {
-        if (mode == 3)
+        if (mode == 4)
+            RTX_LAUNCH(true, 4)
+        else if (mode == 3)
             RTX_LAUNCH(true, 3)
         else if (mode == 2)
             RTX_LAUNCH(true, 2)
@@ -1718,7 +2434,9 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode)
         else
             RTX_LAUNCH(true, 0)
     } else {
-        if (mode == 3)
+        if (mode == 4)
+            RTX_LAUNCH(false, 4)
+        else if (mode == 3)
             RTX_LAUNCH(false, 3)
         else if (mode == 2)
             RTX_LAUNCH(false, 2)
@@ -1986,6 +2704,81 @@ bool cullRectangle(const float* boxLo, const float* boxHi, const rtx_camera* cam
     return true;
 }
 
+// Memory of a deferred frame: a head per camera sample, and pools for shading points, their
+// lights' results and the tapes, sized from the frame (half as many shading points as camera
+// samples, two tape chunks per point) and doubled after a frame that ran over.
+int ensureDeferPools(DeviceCtx* c, size_t headWords, uint32_t nCounting)
+{
+    DeviceCtx::DeferPools& P = c->defer;
+    if (!P.counters) {
+        HIP_TRY(hipMalloc((void**)&P.counters, kDeferControlWords * sizeof(uint32_t)));
+        if (hipHostMalloc((void**)&P.overflowHost, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            P.overflowHost = nullptr; // (the pools then never grow: such frames keep falling back)
+        } else {
+            *P.overflowHost = 0;
+        }
+    }
+    if (P.overflowHost && *P.overflowHost) { // the previous deferred frame ran over
+        P.wantPoints = std::min<uint64_t>(uint64_t(P.pointsPerPool) * 2, (1ull << 28) / kPools);
+        *P.overflowHost = 0;
+    }
+    uint64_t perPool = std::min<uint64_t>(std::max<uint64_t>(headWords / 2, 1ull << 20), 1ull << 25) / kPools;
+    perPool = std::max<uint64_t>(perPool, P.wantPoints);
+    if (const char* e = getenv("RTX_DEFER_POINTS")) // diagnostic: shading points per pool
+        perPool = uint64_t(std::max(1, atoi(e)));
+    const bool growHeads = headWords > P.headWords, growPools = perPool > P.pointsPerPool || (getenv("RTX_DEFER_POINTS") && perPool != P.pointsPerPool), growContrib = growPools || nCounting > P.contribLights;
+    if (growHeads || growPools || growContrib)
+        HIP_TRY(hipStreamSynchronize(c->stream)); // nothing queued may still use what is freed below
+    if (growHeads) {
+        if (P.heads)
+            (void)hipFree(P.heads);
+        P.heads = nullptr;
+        P.headWords = 0;
+        HIP_TRY(hipMalloc((void**)&P.heads, headWords * sizeof(uint32_t)));
+        P.headWords = headWords;
+    }
+    if (growPools) {
+        if (P.points)
+            (void)hipFree(P.points);
+        if (P.tape)
+            (void)hipFree(P.tape);
+        P.points = nullptr;
+        P.tape = nullptr;
+        P.pointsPerPool = P.tapePerPool = 0;
+        HIP_TRY(hipMalloc((void**)&P.points, size_t(perPool) * kPools * sizeof(ShadePoint)));
+        if (hipMalloc((void**)&P.tape, size_t(perPool) * 2 * kPools * kTapeChunk * sizeof(TapeEntry)) != hipSuccess) {
+            (void)hipFree(P.points);
+            P.points = nullptr;
+            setErr("out of device memory for the deferred frame's pools");
+            return RTX_ERR_DEVICE;
+        }
+        P.pointsPerPool = uint32_t(perPool);
+        P.tapePerPool = uint32_t(perPool * 2);
+    }
+    if (growContrib) {
+        if (P.contrib)
+            (void)hipFree(P.contrib);
+        P.contrib = nullptr;
+        P.contribLights = 0;
+        HIP_TRY(hipMalloc((void**)&P.contrib, size_t(P.pointsPerPool) * kPools * nCounting * 3 * sizeof(float)));
+        P.contribLights = nCounting;
+    }
+    return RTX_OK;
+}
+
+template <int STACK>
+void launchLights(DeviceCtx* c, const LightArgs& L, bool count)
+{
+    if (count) {
+        const int grid = gridFor(c, (const void*)lightKernel<STACK, true>);
+        hipLaunchKernelGGL((lightKernel<STACK, true>), dim3(grid), dim3(kBlock), 0, c->stream, L);
+    } else {
+        const int grid = gridFor(c, (const void*)lightKernel<STACK, false>);
+        hipLaunchKernelGGL((lightKernel<STACK, false>), dim3(grid), dim3(kBlock), 0, c->stream, L);
+    }
+}
+
 int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features* f, const rtx_render_params* p, float* dOut, bool compact, rtx_stats* stats, double t0, bool fixedArena = false)
 {
     DeviceCtx* c = g_ctx;
@@ -2052,7 +2845,31 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // With area lights every shading point costs the wave a traversal step per 64
     // light samples however few camera samples it carries, so a unit holds few
     // pixels: short units balance better and their camera rays are the small part.
-    if (f->enable_soft_shadow && scene->hasAreaLight && A.shadowSamples >= 16) {
+    // Frames with area lights are rendered in three passes (walk, lights, resolve: see Deferred)
+    // where the walk's control flow covers the features in play.
+    uint32_t nCounting = 0, drawsPerPoint = 0;
+    for (const int32_t type : scene->lightTypes)
+        if (type == RTX_LIGHT_POINT) {
+            nCounting++;
+        } else if (f->enable_soft_shadow) { // segment / parallelogram lights only count with soft shadows (src/light.cpp:154,167)
+            nCounting++;
+            drawsPerPoint += (type == RTX_LIGHT_SEGMENT ? 1u : 2u) * uint32_t(A.shadowSamples);
+        }
+    const uint64_t outPixels = compact ? uint64_t(g.tilesMine) * g.ts * g.ts : uint64_t(A.W) * uint64_t(A.H);
+    const bool deferred = !fixedArena && f->enable_shading && f->enable_soft_shadow && scene->hasAreaLight && !f->enable_environment_mapping
+        && driver != RTX_DRIVER_TRANSPARENCY && nCounting >= 1 && nCounting <= uint32_t(kMaxDeferLights) && outPixels * uint64_t(A.samples) < 0xffffffffull
+        && g.tilesMine > 0 && !getenv("RTX_NO_DEFER");
+    if (deferred && f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1) {
+        // A deferred frame's walk is bound by its deepest camera sample, whose tree of up to
+        // glossyRays^depth shading points is walked in order (the draws are numbered along that
+        // walk): the deeper the tree, the fewer pixels share a wave, so that a wave serves few
+        // fans per pass and the frame does not wait for waves that hold several deep pixels.
+        double tree = 1;
+        for (int i = 0; i < A.depth && tree < 1e6; i++)
+            tree *= A.glossyRays;
+        A.pixelsPerUnit = std::min(A.pixelsPerUnit, tree <= 25 ? 8 : tree <= 125 ? 2 : 1);
+    }
+    if (f->enable_soft_shadow && scene->hasAreaLight && A.shadowSamples >= 16 && !deferred) {
         A.pixelsPerUnit = std::min(A.pixelsPerUnit, 8);
         // Under glossy recursion a camera sample walks a tree of up to glossyRays^depth
         // shading points one after the other (its draws are numbered in that order), and the
@@ -2091,6 +2908,33 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     const bool fans = f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1 && A.glossyRays <= kFanMax
         && A.pixelsPerUnit * A.lanesPerPixel <= 8 && !getenv("RTX_NO_FANS");
     const int mode = !full ? 0 : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
+    A.runIf = nullptr;
+    A.defer = Deferred {};
+    size_t walkLds = 0;
+    if (deferred) {
+        if (int rc = ensureDeferPools(c, size_t(outPixels) * size_t(A.samples), nCounting))
+            return rc;
+        const DeviceCtx::DeferPools& P = c->defer;
+        A.defer.heads = P.heads;
+        A.defer.tape = P.tape;
+        A.defer.points = P.points;
+        A.defer.contrib = P.contrib;
+        A.defer.counters = P.counters;
+        A.defer.tapePerPool = P.tapePerPool;
+        A.defer.pointsPerPool = P.pointsPerPool;
+        A.defer.nCounting = nCounting;
+        A.defer.drawsPerPoint = drawsPerPoint;
+        // glossy fans traced side by side: their hits wait in LDS, for as many levels as 64 KB hold
+        // (deeper fans, and scenes with spheres, whose hits are not triangle records: ray by ray)
+        A.defer.fanLevels = 0;
+        A.defer.leafFans = getenv("RTX_NO_LEAF_FANS") ? 0u : 1u; // (diagnostic switch)
+        A.defer.fansTogether = A.pixelsPerUnit * A.lanesPerPixel <= 2 ? 1u : 0u;
+        if (f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1 && A.glossyRays <= kFanMax && scene->d.nSpheres == 0 && !getenv("RTX_NO_FANS")) {
+            const size_t perLevel = size_t(A.glossyRays) * kBlock * 8;
+            A.defer.fanLevels = uint32_t(std::min<size_t>(size_t(A.depth), (64 * 1024) / perLevel));
+            walkLds = size_t(A.defer.fanLevels) * perLevel;
+        }
+    }
 
     // wave-uniform block arithmetic and the culling rectangle
     A.unitsPerBlockLog2 = -1;
@@ -2251,16 +3095,83 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     }
     if (!ordered)
         HIP_TRY(hipMemsetAsync(a->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
+    const bool count = wantCounters();
+    auto launch = [&](const RenderArgs& R, int m, size_t lds) {
+        switch (stack) {
+        case 16: launchRender<16>(c, R, count, m, lds); break;
+        case 24: launchRender<24>(c, R, count, m, lds); break;
+        case 32: launchRender<32>(c, R, count, m, lds); break;
+        default: launchRender<64>(c, R, count, m, lds); break;
+        }
+    };
+    if (deferred && A.work.nUnits) {
+        const Deferred& D = A.defer;
+        HIP_TRY(hipMemsetAsync(D.heads, 0xff, size_t(outPixels) * size_t(A.samples) * sizeof(uint32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(D.counters, 0, kDeferControlWords * sizeof(uint32_t), c->stream));
+        if (stats)
+            HIP_TRY(hipEventRecord(c->ev0, c->stream)); // kernel_ms covers the three passes
+        launch(A, 4, walkLds);
+        HIP_TRY(hipGetLastError());
+        uint32_t slot = 0, offset = 0;
+        for (size_t li = 0; li < scene->lightTypes.size(); li++) {
+            const int32_t type = scene->lightTypes[li];
+            if (type != RTX_LIGHT_POINT && !f->enable_soft_shadow)
+                continue;
+            uint32_t* const control = D.counters + kDeferCounterWords + size_t(slot) * (kDeferTicketWords + kDeferUnitWords + kDeferPlanWords);
+            LightArgs L;
+            L.sc = scene->d;
+            L.f = *f;
+            L.defer = D;
+            L.light = int32_t(li);
+            L.slot = int32_t(slot);
+            L.nS = type == RTX_LIGHT_POINT ? 1 : A.shadowSamples;
+            L.counterOffset = offset;
+            L.unitStart = control + kDeferTicketWords;
+            L.work.tickets = control;
+            L.work.nUnits = 0xffffffffu; // (the plan, made on the device after the walk, says how many)
+            L.work.chunk = 1;
+            L.work.nChunks = 0xffffffffu;
+            L.work.plan = control + kDeferTicketWords + kDeferUnitWords;
+            L.work.aheadFrom = 0;
+            L.stats = a->stats;
+            hipLaunchKernelGGL(planLightsKernel, dim3(1), dim3(64), 0, c->stream, D, uint32_t(std::min(L.nS, 64)), control + kDeferTicketWords, control + kDeferTicketWords + kDeferUnitWords);
+            switch (stack) {
+            case 16: launchLights<16>(c, L, count); break;
+            case 24: launchLights<24>(c, L, count); break;
+            case 32: launchLights<32>(c, L, count); break;
+            default: launchLights<64>(c, L, count); break;
+            }
+            HIP_TRY(hipGetLastError());
+            if (type != RTX_LIGHT_POINT)
+                offset += (type == RTX_LIGHT_SEGMENT ? 1u : 2u) * uint32_t(A.shadowSamples);
+            slot++;
+        }
+        ResolveArgs R;
+        R.defer = D;
+        R.out = dOut;
+        R.nPixels = uint32_t(outPixels);
+        R.samples = A.samples;
+        R.driver = driver;
+        hipLaunchKernelGGL(resolveKernel, dim3((R.nPixels + 255u) / 256u), dim3(256), 0, c->stream, R);
+        // A frame whose pools ran over (the flag says so on the device) is rendered again by the
+        // one-kernel path, in the walk's units; that launch returns at once otherwise.
+        hipLaunchKernelGGL(dropCountsIfOverflowKernel, dim3(1), dim3(64), 0, c->stream, D, a->stats);
+        HIP_TRY(hipMemsetAsync(a->tickets, 0, kTicketBytes, c->stream));
+        RenderArgs B = A;
+        B.defer = Deferred {};
+        B.runIf = deferOverflow(D);
+        launch(B, (fans && A.pixelsPerUnit * A.lanesPerPixel <= 8) ? 3 : 1, 0);
+        HIP_TRY(hipGetLastError());
+        if (c->defer.overflowHost)
+            HIP_TRY(hipMemcpyAsync(c->defer.overflowHost, deferOverflow(D), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (stats)
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        return fetchStats(c, a, stats, t0);
+    }
     if (stats) // (an event record costs the stream a few microseconds around the kernel: only when the time is asked for)
         HIP_TRY(hipEventRecord(c->ev0, c->stream)); // kernel_ms is the render kernel's time
     if (A.work.nUnits) {
-        const bool count = wantCounters();
-        switch (stack) {
-        case 16: launchRender<16>(c, A, count, mode); break;
-        case 24: launchRender<24>(c, A, count, mode); break;
-        case 32: launchRender<32>(c, A, count, mode); break;
-        default: launchRender<64>(c, A, count, mode); break;
-        }
+        launch(A, mode, 0);
         HIP_TRY(hipGetLastError());
     }
     if (stats)
@@ -2783,8 +3694,10 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     s->d.nTris = int32_t(d->n_tris);
     s->d.nLights = int32_t(d->n_lights);
     s->d.nEnvBins = int32_t(d->n_env_bins);
-    for (uint32_t i = 0; i < d->n_lights; i++)
+    for (uint32_t i = 0; i < d->n_lights; i++) {
         s->hasAreaLight = s->hasAreaLight || d->lights[i].type != RTX_LIGHT_POINT;
+        s->lightTypes.push_back(d->lights[i].type);
+    }
     s->d.nSpheres = int32_t(d->n_spheres);
     s->d.nMaterials = int32_t(d->n_materials);
     s->d.rootRef = (d->root_ref < 0 && d->root_ref != kEmptyRoot) ? ~int32_t(d->n_nodes + uint32_t(~d->root_ref)) : d->root_ref;

@@ -134,7 +134,8 @@ def test_get_final_color_matches_reference_and_oracle(gpu_device, golden_shade):
 
 @pytest.mark.parametrize("samples", [1, 3, 16, 50, 64, 100, 130])
 def test_area_light_sample_counts(gpu_device, samples):
-    """Segment and parallelogram lights are sampled by the whole wave: sample
+    """Segment and parallelogram lights are sampled by a wave's lanes side by side
+    (in the light pass of a deferred frame, or inside the one-kernel path): sample
     counts that pack several shading points into one wave step (<= 32), leave
     lanes idle (50), fill the wave (64) and need several steps per point (> 64)."""
     scene = cases.load_scene("cornell")
@@ -180,8 +181,93 @@ def test_glossy_fans_traced_side_by_side(gpu_device, glossy_rays, depth, monkeyp
     monkeypatch.setenv("RTX_NO_FANS", "1")
     plain = gpu.render(cam, f, rp)
     assert np.array_equal(np.isnan(plain), np.isnan(got)) and np.array_equal(np.nan_to_num(plain), np.nan_to_num(got))
+    # the fans that end the recursion, finished by the lanes that traced them or ray by ray
+    monkeypatch.delenv("RTX_NO_FANS")
+    monkeypatch.setenv("RTX_NO_LEAF_FANS", "1")
+    plain = gpu.render(cam, f, rp)
+    assert np.array_equal(np.isnan(plain), np.isnan(got)) and np.array_equal(np.nan_to_num(plain), np.nan_to_num(got))
+    assert (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce) == rays_gpu
     gpu.close()
     orc.close()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_deferred_light_sampling_equals_the_one_kernel_path(gpu_device, monkeypatch):
+    """Frames with area lights are rendered in three passes (walk of the radiance rays, light
+    sampling for all shading points of the frame, replay of the samples' tapes).  The result
+    must be, bit for bit and ray for ray, what the single state-machine kernel gives
+    (RTX_NO_DEFER), which the other tests hold to the oracle: every driver, several lights of
+    all kinds, more than 64 samples per light, mirror and glossy recursion, tile partitions -
+    and also when the frame's pools are too small and the one-kernel path takes over."""
+    import ctypes as C
+    import torch
+    from raytracer_amd import engine
+    hip = engine.hip_lib()
+    scene = cases.load_scene("cornell")
+    scene.lights = [abi.segment_light((0.3, 0.55, -0.2), (-0.3, 0.55, 0.2), (0.9, 0.2, 0.1), (0.2, 1, 0.3)),
+                    abi.point_light((0.0, 0.5, 0.3), (0.3, 0.3, 0.3))] + list(cases._AREA)
+    for m in scene.meshes[::2]:
+        m.material[3:6] = 0.4
+        m.material[6] = 20.0
+    cam = make_camera()
+    prev = make_camera(look_at=(0.0, 0.0, 0.3))
+    jobs = [
+        ("glossy depth 3", dict(recursive=1, glossy_reflection=1), dict(shadow_samples=16, glossy_rays=5, ray_depth=3)),
+        ("mirror depth 4", dict(recursive=1), dict(shadow_samples=70, ray_depth=4)),
+        ("no hard shadows", dict(hard_shadow=0, recursive=1, glossy_reflection=1), dict(shadow_samples=8, glossy_rays=9, ray_depth=2)),
+        ("jittered 4 spp", dict(recursive=1, glossy_reflection=1), dict(driver=abi.DRIVER_MRAYS, samples=4, shadow_samples=32, glossy_rays=3, ray_depth=2)),
+        ("depth of field 70 samples", dict(), dict(driver=abi.DRIVER_DOF, samples=70, shadow_samples=5)),
+        ("motion blur", dict(recursive=1), dict(driver=abi.DRIVER_MOTION_BLUR, samples=7, shadow_samples=16, prev_camera=prev)),
+    ]
+    for name, feat, params in jobs:
+        f = abi.features(**dict(cases.BASE, soft_shadow=1, **feat))
+        rp = make_params(56, 40, **params)
+        gpu = GpuEngine(scene, f)
+        frames, counts = {}, {}
+        for mode, env in (("deferred", {}), ("one kernel", {"RTX_NO_DEFER": "1"}), ("pools too small", {"RTX_DEFER_POINTS": "3"})):
+            for k in ("RTX_NO_DEFER", "RTX_DEFER_POINTS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            frames[mode] = gpu.render(cam, f, rp)
+            st = gpu.stats
+            counts[mode] = (st.rays_primary, st.rays_shadow, st.rays_bounce, st.shaded_hits, st.rays_traced)
+        for k in ("RTX_NO_DEFER", "RTX_DEFER_POINTS"):
+            monkeypatch.delenv(k, raising=False)
+        for mode in ("deferred", "pools too small"):
+            assert np.array_equal(_bits(frames[mode]), _bits(frames["one kernel"])), f"{name}: {mode} frame differs from the one-kernel frame"
+            assert counts[mode] == counts["one kernel"], f"{name}: {mode} counts {counts[mode]} vs {counts['one kernel']}"
+        assert counts["deferred"][1] > 0 and np.nanmax(frames["deferred"]) > 0
+        # a later frame on pools that have grown is the same again
+        assert np.array_equal(_bits(gpu.render(cam, f, rp)), _bits(frames["one kernel"])), name
+        gpu.close()
+    # tile partitions: every rank's compact buffer, de-tiled, is the whole frame
+    f = abi.features(**dict(cases.BASE, soft_shadow=1, recursive=1, glossy_reflection=1))
+    gpu = GpuEngine(scene, f)
+    w, h, ts = 72, 40, 16
+    dcam = engine.device_camera(cam, w, h)
+    dev = torch.device("cuda", 0)
+    whole = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    kw = dict(driver=abi.DRIVER_MRAYS, samples=2, shadow_samples=16, glossy_rays=3, ray_depth=2, tile_size=ts)
+    st = abi.Stats()
+    assert hip.rtx_render_device(gpu.device_scene(), C.byref(dcam), C.byref(f), C.byref(make_params(w, h, **kw)), C.c_void_p(whole.data_ptr()), C.byref(st)) == 0
+    total = (st.rays_primary, st.rays_shadow, st.rays_bounce)
+    world = 3
+    per = hip.rtx_tiles_per_rank(C.byref(make_params(w, h, tile_size=ts, tile_world=world)))
+    stack = torch.zeros((world, per, ts, ts, 3), dtype=torch.float32, device=dev)
+    summed = [0, 0, 0]
+    for rank in range(world):
+        rp = make_params(w, h, tile_rank=rank, tile_world=world, **kw)
+        assert hip.rtx_render_tiles_device(gpu.device_scene(), C.byref(dcam), C.byref(f), C.byref(rp), C.c_void_p(stack[rank].data_ptr()), C.byref(st)) == 0
+        summed = [a + b for a, b in zip(summed, (st.rays_primary, st.rays_shadow, st.rays_bounce))]
+    out = torch.zeros_like(whole)
+    assert hip.rtx_detile_device(C.c_void_p(stack.data_ptr()), C.byref(make_params(w, h, tile_size=ts, tile_world=world)), C.c_void_p(out.data_ptr())) == 0
+    assert hip.rtx_synchronize() == 0
+    assert torch.equal(out, whole) and tuple(summed) == total
+    gpu.close()
 
 
 def test_shadow_query_shortcuts_do_not_change_frames(gpu_device):
