@@ -43,7 +43,7 @@ def algorithmic_bytes(stats_rays, shaded, pixels, n_aabb, n_tri):
     return stats_rays * (28.0 + 24.0 * n_aabb + 36.0 * n_tri + 16.0) + shaded * (3 * 32 + 32) + pixels * 12.0
 
 
-def cpu_baseline(scene, features, cam, args):
+def cpu_baseline(scene, features, cam, args, wl):
     """The CPU path timed on this box's host cores on a bounded sample of the same
     workload: the reference's own renderRayTracingMRaysPerPixel when oracle/_ref
     was built and shipped, else the CPU restatement.  Also returns the per-ray
@@ -54,7 +54,9 @@ def cpu_baseline(scene, features, cam, args):
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     orc = OracleEngine(scene, features)
     # per-ray work of the reference's visit rule on a 1/16-area frame of the same view
-    small = make_params(args.width // 4, args.height // 4, driver=abi.DRIVER_MRAYS, samples=args.spp)
+    shrink = 4 if args.workload == "headline" else 16 # (the other workloads cost more per pixel)
+    small = make_params(args.width // shrink, args.height // shrink, **wl["params"])
+    mode = dict(mode=wl["ref_mode"])                  # 1: the harness's pixel loop around the reference's getFinalColor (depth, keyed draws)
     orc.render(cam, features, small, threads=threads)
     c = orc.counters.astype(np.float64)
     rays_small = c[0] + c[1] + c[2]
@@ -63,13 +65,13 @@ def cpu_baseline(scene, features, cam, args):
     kind = eng.kind
     # probe, then size the sample for roughly 15 s of CPU work
     t0 = time.perf_counter()
-    eng.render(cam, features, small, threads=threads)
+    eng.render(cam, features, small, threads=threads, **mode)
     probe = time.perf_counter() - t0
     scale = min(4.0, max(1.0, (15.0 / max(probe, 1e-3)) ** 0.5))
     w, h = int(small.width * scale) // 8 * 8, int(small.height * scale) // 8 * 8
-    sample = make_params(w, h, driver=abi.DRIVER_MRAYS, samples=args.spp)
+    sample = make_params(w, h, **wl["params"])
     t0 = time.perf_counter()
-    eng.render(cam, features, sample, threads=threads)
+    eng.render(cam, features, sample, threads=threads, **mode)
     dt = time.perf_counter() - t0
     orc.render(cam, features, sample, threads=threads)
     rays = float(orc.counters[:3].sum())
@@ -77,8 +79,44 @@ def cpu_baseline(scene, features, cam, args):
     if eng is not orc:
         eng.close()
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind=kind,
-                sample=f"{w}x{h} frame of the same scene/camera, {args.spp} spp, {int(rays)} rays in {dt:.2f} s "
-                       f"({'reference renderRayTracingMRaysPerPixel, OpenMP' if kind == 'reference' else 'CPU restatement, OpenMP'})"), n_aabb, n_tri
+                sample=f"{w}x{h} frame of the same scene/camera and parameters, {int(rays)} rays in {dt:.2f} s "
+                       f"({('reference renderRayTracingMRaysPerPixel, OpenMP' if wl['ref_mode'] == 0 else 'reference getFinalColor in a pixel loop, OpenMP') if kind == 'reference' else 'CPU restatement, OpenMP'})"), n_aabb, n_tri
+
+
+def workload(name, args):
+    """The scene, features, frame parameters and description of a workload:
+    headline      BASELINE configs[1] (the metric's own configuration; the default)
+    area_glossy   BASELINE configs[2]: the same mesh with a glossy material under one parallelogram
+                  light, 64 shadow samples, glossy reflections (fans of 5) to depth 4, 1 spp
+    big_scene     BASELINE configs[4]'s geometry: 122 instances of the mesh baked to 9 994 240
+                  triangles, 3840x2160, 16 spp jittered"""
+    from raytracer_amd import abi
+    from raytracer_amd.scene import SceneData, dragon_scene, instanced_scene
+    base = dict(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
+    if name == "headline":
+        scene = SceneData.load(args.obj_npz) if args.obj_npz else dragon_scene()
+        return dict(scene=scene, features=abi.features(**base), params=dict(driver=abi.DRIVER_MRAYS, samples=args.spp), ref_mode=0,
+                    metric="Mrays/s (primary+secondary), dragon 1080p 16spp",
+                    text=f"dragon stand-in ({scene.n_triangles} tris, seeded; dragon.obj is absent from the reference checkout) "
+                         f"{args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light")
+    if name == "area_glossy":
+        scene = dragon_scene()
+        scene.lights = [abi.parallelogram_light((-0.2, 0.9, 0.0), (0.4, 0, 0), (0, 0, 0.4), (1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1))]
+        for m in scene.meshes:   # a glossy material: ks != 0, shininess 50
+            m.material[3:6] = 0.5
+            m.material[6] = 50.0
+        f = abi.features(**dict(base, hard_shadow=0, soft_shadow=1, recursive=1, glossy_reflection=1))
+        return dict(scene=scene, features=f, params=dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=4), ref_mode=1,
+                    metric="Mrays/s (primary+secondary), dragon 1080p area light 64 + glossy depth 4",
+                    text=f"dragon stand-in ({scene.n_triangles} tris, seeded, ks 0.5, shininess 50) {args.width}x{args.height}, 1 spp, "
+                         "one parallelogram light with 64 shadow samples, glossy reflections (5 rays) to depth 4")
+    if name == "big_scene":
+        scene = instanced_scene(122)
+        return dict(scene=scene, features=abi.features(**base), params=dict(driver=abi.DRIVER_MRAYS, samples=args.spp), ref_mode=0,
+                    metric="Mrays/s (primary+secondary), 10 M triangles 3840x2160 16spp",
+                    text=f"122 instances of the dragon stand-in baked to {scene.n_triangles} triangles, {args.width}x{args.height}, "
+                         f"{args.spp} spp jittered, Phong + hard shadows, 1 point light")
+    sys.exit(f"unknown workload {name}")
 
 
 def valu_peak(waves_per_simd=4):
@@ -117,7 +155,11 @@ def main():
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-GPU render of it")
     ap.add_argument("--no-every-block", action="store_true", help="skip the second timing of the frame with no block declared unable to see the scene (roofline.kernel_ms_every_block_traced)")
     ap.add_argument("--force-pipeline", action="store_true", help="rehearsal: run the N > 1 code path (tiles, gather, assembly) in a one-rank group")
+    ap.add_argument("--workload", default="headline", choices=["headline", "area_glossy", "big_scene"],
+                    help="headline = BASELINE configs[1], the metric's configuration; area_glossy = configs[2]; big_scene = configs[4]'s geometry")
     args = ap.parse_args()
+    if args.workload == "big_scene" and (args.width, args.height) == (1920, 1080):
+        args.width, args.height = 3840, 2160
 
     import torch
     import torch.distributed as dist
@@ -149,8 +191,8 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     hip = engine.hip_lib()
-    scene = SceneData.load(args.obj_npz) if args.obj_npz else dragon_scene()
-    features = abi.features(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
+    wl = workload(args.workload, args)
+    scene, features = wl["scene"], wl["features"]
     cam_in = make_camera()
 
     t_build = time.perf_counter()
@@ -158,8 +200,7 @@ def main():
     t_build = time.perf_counter() - t_build
     dscene = gpu.device_scene()
     cam = engine.device_camera(cam_in, args.width, args.height)
-    rp = make_params(args.width, args.height, driver=abi.DRIVER_MRAYS, samples=args.spp, tile_size=args.tile,
-                     tile_rank=rank, tile_world=world)
+    rp = make_params(args.width, args.height, tile_size=args.tile, tile_rank=rank, tile_world=world, **wl["params"])
     # queue the library's work on a torch stream so events and collectives order with it
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -242,7 +283,7 @@ def main():
 
     if rank == 0 and args.check and grouped:
         ref = torch.zeros_like(frame)
-        one = make_params(args.width, args.height, driver=abi.DRIVER_MRAYS, samples=args.spp, tile_size=args.tile)
+        one = make_params(args.width, args.height, tile_size=args.tile, **wl["params"])
         rc = hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(one), C.c_void_p(ref.data_ptr()), None)
         torch.cuda.synchronize()
         assert rc == 0 and torch.equal(ref, frame), "assembled multi-rank frame differs from the single-GPU frame"
@@ -250,14 +291,12 @@ def main():
     if rank == 0:
         value = rays_frame * args.steps / elapsed / 1e6
         out = {
-            "metric": "Mrays/s (primary+secondary), dragon 1080p 16spp",
+            "metric": wl["metric"],
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"dragon stand-in ({scene.n_triangles} tris, seeded; dragon.obj is absent from the reference checkout) "
-                                   f"{args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light, sweep-split BVH "
-                                   f"({gpu.levels()} levels, {gpu.leaves()} leaves)",
-                       "rays_per_frame": int(rays_frame), "primary": int(counts[0]), "shadow": int(counts[1]),
+            "config": {"workload": wl["text"] + f", sweep-split BVH ({gpu.levels()} levels, {gpu.leaves()} leaves)",
+                       "rays_per_frame": int(rays_frame), "primary": int(counts[0]), "shadow": int(counts[1]), "bounce": int(counts[2]),
                        # one "ray" = one BvhInterface::intersect call of the reference.  The device does not make
                        # the camera rays of 8x8 blocks that cannot see the scene's bounds (the reference tests
                        # and misses them): rays_traced are the rays that did walk the scene on the device
@@ -268,15 +307,15 @@ def main():
         if not grouped:
             cb, n_aabb, n_tri = (None, None, None)
             if not args.no_cpu_baseline:
-                cb, n_aabb, n_tri = cpu_baseline(scene, features, cam_in, args)
+                cb, n_aabb, n_tri = cpu_baseline(scene, features, cam_in, args, wl)
             # measured counters of the same command, committed with the rocprofv3 summaries they come from
             traffic, valu_instr = None, None
             tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and args.workload == "headline":
                 with open(tpath) as fh:
                     traffic = json.load(fh).get("bytes_per_launch")
             cpath = os.path.join(ROOT, "profiles", "r02_render_counters.json")
-            if os.path.exists(cpath):
+            if os.path.exists(cpath) and args.workload == "headline":
                 with open(cpath) as fh:
                     valu_instr = json.load(fh).get("counters_per_launch_mean", {}).get("SQ_INSTS_VALU")
             if n_aabb is not None:
@@ -284,7 +323,8 @@ def main():
                 achieved = alg / (kernel_ms * 1e-3) / 1e9
                 out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                                   "kernel": "renderKernel", "kernel_ms": round(kernel_ms, 4),
+                                   "kernel": "renderKernel" if args.workload != "area_glossy" else "renderKernel (walk) + lightKernel + resolveKernel",
+                                   "kernel_ms": round(kernel_ms, 4),
                                    "algorithmic_bytes_per_launch": int(alg), "box_tests_per_ray": round(n_aabb, 3),
                                    "tri_tests_per_ray": round(n_tri, 3)}
                 if traffic is not None:

@@ -478,6 +478,14 @@ RTX_DEV PixelPlace placePixel(const RenderArgs& A, uint32_t unit, int slot, bool
     return pl;
 }
 
+// One pixel (or one point's light result): three floats with ONE 12-byte store, so that
+// a wave writing neighbouring pixels covers whole lines with a single instruction instead of
+// three strided ones.
+struct __attribute__((packed, aligned(4))) Rgb {
+    float r, g, b;
+};
+RTX_DEV void storeRgb(float* dst, V3 c) { *reinterpret_cast<Rgb*>(dst) = Rgb { c.x, c.y, c.z }; }
+
 RTX_DEV float fromLane(float v, int lane) // lane: wave-uniform
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -1541,9 +1549,7 @@ __global__ void __launch_bounds__(kBlock, MODE == 0 ? RTX_LEAN_WAVES : MODE == 4
         lc.primary += uint32_t(__popcll(__ballot(ok))) * uint32_t(A.samples);
         if (ok) {
             float* dst = A.out + size_t(blockPixelIndex(A, b, mx, my)) * 3;
-            dst[0] = 0.0f;
-            dst[1] = 0.0f;
-            dst[2] = 0.0f;
+            storeRgb(dst, mk(0, 0, 0));
         }
     };
     WorkCursor cursor;
@@ -1589,9 +1595,7 @@ __global__ void __launch_bounds__(kBlock, MODE == 0 ? RTX_LEAN_WAVES : MODE == 4
                 lc.countPrimary(place.ok && round * A.lanesPerPixel + sub < A.samples);
             if (writer && place.ok) {
                 float* dst = A.out + size_t(place.outIndex) * 3;
-                dst[0] = 0.0f;
-                dst[1] = 0.0f;
-                dst[2] = 0.0f;
+                storeRgb(dst, mk(0, 0, 0));
             }
             continue;
         }
@@ -1728,9 +1732,7 @@ __global__ void __launch_bounds__(kBlock, MODE == 0 ? RTX_LEAN_WAVES : MODE == 4
                     px = accum / float(A.samples);
                 }
                 float* dst = A.out + size_t(outIndex) * 3;
-                dst[0] = px.x;
-                dst[1] = px.y;
-                dst[2] = px.z;
+                storeRgb(dst, px);
             }
         }
 #ifdef RTX_PROBE
@@ -2037,9 +2039,7 @@ __global__ void __launch_bounds__(kBlock, RTX_LIGHT_WAVES) lightKernel(LightArgs
             const int lastSample = isPoint ? 0 : min(group, nS - (rounds - 1) * 64) - 1;
             if (valid && mySample == lastSample) {
                 float* dst = D.contrib + (size_t(point) * D.nCounting + uint32_t(L.slot)) * 3;
-                dst[0] = result.x;
-                dst[1] = result.y;
-                dst[2] = result.z;
+                storeRgb(dst, result);
             }
         }
     }
@@ -2125,9 +2125,7 @@ __global__ void __launch_bounds__(256) resolveKernel(ResolveArgs R)
         px = resolveTape(D, heads[0]); // (not a sum: the one sample as it is, -0 included)
     }
     float* dst = R.out + size_t(i) * 3;
-    dst[0] = px.x;
-    dst[1] = px.y;
-    dst[2] = px.z;
+    storeRgb(dst, px);
 }
 // A deferred frame whose pools ran over is rendered again by the one-kernel path, which counts
 // its rays itself: the walk's counts are dropped.  One wave.
