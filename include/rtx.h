@@ -242,6 +242,25 @@ int rtx_init(int device);
  * BvhInterface::BvhInterface (src/bvh_interface.cpp:6-9): the host has built
  * the tree, this copies it to HBM.  Returns NULL on failure. */
 rtx_scene* rtx_scene_create(const rtx_scene_desc* desc);
+/* The same scene with its tree built on the GPU instead.  Replaces the whole of
+ * BoundingVolumeHierarchy's constructor and bvhSplitHelper
+ * (src/bounding_volume_hierarchy.cpp:101-180) for callers that cannot wait for the host
+ * builder (10 M triangles): desc->tris / desc->tri_attrs hold the triangles in id order
+ * (record i has id i, planes filled in, flags ignored), desc->nodes and root_* are ignored.
+ * The tree is a linear BVH over Morton codes with leaves of up to four triangles (more where
+ * triangles crowd), NOT the reference's tree: closest hits, and with them every frame, are
+ * the same except where two triangles tie at exactly the same distance; numLevels /
+ * numLeaves are this tree's (see rtx_scene_tree_info).  Returns NULL on failure. */
+rtx_scene* rtx_scene_build_device(const rtx_scene_desc* desc);
+/* BvhInterface::numLevels / numLeaves (src/bvh_interface.cpp:12-23) of the tree the scene
+ * holds: the description's numbers after rtx_scene_create, the built tree's after
+ * rtx_scene_build_device. */
+typedef struct rtx_tree_info {
+    int32_t levels, leaves;
+    float   upload_ms;  /* rtx_scene_build_device: copying the triangle records to the GPU (0 otherwise) */
+    float   build_ms;   /* rtx_scene_build_device: sorting, hierarchy, boxes, records (0 otherwise)       */
+} rtx_tree_info;
+int rtx_scene_tree_info(const rtx_scene* scene, rtx_tree_info* info);
 /* BvhInterface is trivially copyable in the reference (src/main.cpp:218
  * re-assigns it), so handles are reference-counted. */
 void rtx_scene_retain(rtx_scene* scene);

@@ -316,31 +316,60 @@ RTX_DEV TriRec loadTri(const DScene& sc, int k)
 }
 
 // --------------------------------------------------------------- traversal --
-// Per-lane traversal stack in LDS: entry e of lane l lives at stack[e][l], so a
-// wave's 64 lanes always touch 64 different banks whatever their stack depths.
+// Per-lane traversal stack: the first kLdsStack entries of a lane live in LDS, entry e of lane l
+// at stack[e][l], so a wave's 64 lanes always touch 64 different banks whatever their stack
+// depths; deeper entries (trees of more than kLdsStack levels, and there only the walks that
+// really leave that many subtrees pending) go to the lane's own scratch memory.  The LDS a
+// workgroup takes, and with it the number of waves a CU holds, thus does not grow with the
+// tree's depth: with all entries in LDS the 32-entry kernels held half the waves of the
+// 16-entry ones, and the headline frame took 1.32 ms on them instead of 0.91 ms.
+constexpr int kLdsStack = 16;
 template <int STACK>
 struct LaneStack {
-    int32_t* refs;  // [STACK][kBlock]
-    float* keys;    // [STACK][kBlock], directly behind refs: the wave-shared walk uses the two as ONE array of 2 * STACK keys per lane
+    static constexpr int kLds = STACK < kLdsStack ? STACK : kLdsStack;
+    static constexpr int kOver = STACK > kLdsStack ? STACK - kLdsStack : 1;
+    int32_t* refs;  // [kLds][kBlock]
+    float* keys;    // [kLds][kBlock], directly behind refs: the wave-shared walk uses the two as ONE array of 2 * kLds keys per lane
     int tid;
     int32_t* waveRefs; // [2 * STACK] of this wave: the wave-shared walk's subtree references (the same for every lane)
+    int32_t overRefs[kOver];
+    float overKeys[kOver];
+    float overWaveKeys[2 * kOver];
     // the wave-shared walk's entries: a key per lane, one reference per wave
     RTX_DEV void pushWave(int sp, int32_t ref, float key)
     {
-        reinterpret_cast<float*>(refs)[sp * kBlock + tid] = key;
+        if (STACK <= kLdsStack || sp < 2 * kLds)
+            reinterpret_cast<float*>(refs)[sp * kBlock + tid] = key;
+        else
+            overWaveKeys[sp - 2 * kLds] = key;
         waveRefs[sp] = ref;
     }
-    RTX_DEV float waveKey(int sp) const { return reinterpret_cast<const float*>(refs)[sp * kBlock + tid]; }
+    RTX_DEV float waveKey(int sp) const
+    {
+        if (STACK <= kLdsStack || sp < 2 * kLds)
+            return reinterpret_cast<const float*>(refs)[sp * kBlock + tid];
+        return overWaveKeys[sp - 2 * kLds];
+    }
     RTX_DEV int32_t waveRef(int sp) const { return __builtin_amdgcn_readfirstlane(waveRefs[sp]); }
     RTX_DEV void push(int sp, int32_t ref, float key)
     {
-        refs[sp * kBlock + tid] = ref;
-        keys[sp * kBlock + tid] = key;
+        if (STACK <= kLdsStack || sp < kLds) {
+            refs[sp * kBlock + tid] = ref;
+            keys[sp * kBlock + tid] = key;
+        } else {
+            overRefs[sp - kLds] = ref;
+            overKeys[sp - kLds] = key;
+        }
     }
     RTX_DEV void pop(int sp, int32_t& ref, float& key)
     {
-        ref = refs[sp * kBlock + tid];
-        key = keys[sp * kBlock + tid];
+        if (STACK <= kLdsStack || sp < kLds) {
+            ref = refs[sp * kBlock + tid];
+            key = keys[sp * kBlock + tid];
+        } else {
+            ref = overRefs[sp - kLds];
+            key = overKeys[sp - kLds];
+        }
     }
 };
 

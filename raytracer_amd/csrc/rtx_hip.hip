@@ -22,6 +22,7 @@
 
 #include "rtx.h"
 #include "rtx_device.hpp"
+#include "rtx_build.hpp"
 
 using namespace rtxd;
 
@@ -224,9 +225,9 @@ struct TraceArgs {
 template <int STACK, bool COUNT>
 __global__ void __launch_bounds__(kBlock) traceKernel(TraceArgs A)
 {
-    __shared__ int32_t sStack[2 * STACK * kBlock];
+    __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
-    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + STACK * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
+    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + LaneStack<STACK>::kLds * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
     LaneCounters lc;
     const int lane = threadIdx.x & 63;
     WorkCursor cursor;
@@ -1526,12 +1527,12 @@ template <int STACK, bool COUNT, int MODE>
 __global__ void __launch_bounds__(kBlock, MODE == 0 ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A)
 {
     constexpr bool FULL = MODE != 0;
-    __shared__ int32_t sStack[2 * STACK * kBlock];
+    __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
     extern __shared__ int32_t sFan[]; // MODE 4: fanLevels * fan size * kBlock distances, then as many triangle records
     if (A.runIf && __hip_atomic_load(A.runIf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
         return;
-    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + STACK * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
+    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + LaneStack<STACK>::kLds * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
     LaneCounters lc;
     const int lane = threadIdx.x & 63;
     const int slot = lane / A.lanesPerPixel, sub = lane % A.lanesPerPixel;
@@ -1948,8 +1949,8 @@ __global__ void __launch_bounds__(64) planLightsKernel(Deferred D, uint32_t grou
 template <int STACK, bool COUNT>
 __global__ void __launch_bounds__(kBlock, RTX_LIGHT_WAVES) lightKernel(LightArgs L)
 {
-    __shared__ int32_t sStack[2 * STACK * kBlock];
-    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + STACK * kBlock), int(threadIdx.x), nullptr };
+    __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
+    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + LaneStack<STACK>::kLds * kBlock), int(threadIdx.x), nullptr };
     LaneCounters lc;
     const DScene& sc = L.sc;
     const Deferred& D = L.defer;
@@ -2148,9 +2149,9 @@ struct ShadeArgs {
 template <int STACK, bool COUNT, bool ENVL>
 __global__ void __launch_bounds__(kBlock, RTX_FULL_WAVES) shadeKernel(ShadeArgs S)
 {
-    __shared__ int32_t sStack[2 * STACK * kBlock];
+    __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
-    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + STACK * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
+    LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + LaneStack<STACK>::kLds * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
     LaneCounters lc;
     const RenderArgs& A = S.R;
     const int lane = threadIdx.x & 63;
@@ -2322,6 +2323,8 @@ struct rtx_scene {
     bool hasEnv = false;
     bool hasAreaLight = false; // a segment or parallelogram light
     std::vector<int32_t> lightTypes;
+    int numLeaves = 0;         // leaves of the tree (the description's count, or the device builder's)
+    float uploadMs = 0.f, buildMs = 0.f; // rtx_scene_build_device: the triangles' way to the GPU, and the build there
     // boxes of a shallow cut through the tree (at most kMaxCutBoxes; every triangle lies
     // in one of them), for the per-frame visibility rectangles
     std::vector<std::array<float, 6>> cutBoxes;
@@ -3252,6 +3255,82 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
     return fetchStats(c, a, stats, t0);
 }
 
+// What both ways of making a scene (rtx_scene_create, rtx_scene_build_device) check of a
+// description besides its tree: everything the kernels index must be in range.
+bool shadingInputsOk(const rtx_scene_desc* d)
+{
+    for (uint32_t i = 0; i < d->n_tris; i++) {
+        if (d->tris[i].material < 0 || uint32_t(d->tris[i].material) >= d->n_materials) {
+            setErr("rtx_scene_create: triangle %u has material %d of %u", i, d->tris[i].material, d->n_materials);
+            return false;
+        }
+        if (d->tris[i].id < 0 || uint32_t(d->tris[i].id) >= d->n_tris) {
+            setErr("rtx_scene_create: triangle %u has id %d of %u", i, d->tris[i].id, d->n_tris);
+            return false;
+        }
+    }
+    for (uint32_t i = 0; i < d->n_spheres; i++)
+        if (d->spheres[i].material < 0 || uint32_t(d->spheres[i].material) >= d->n_materials) {
+            setErr("rtx_scene_create: sphere %u has material %d of %u", i, d->spheres[i].material, d->n_materials);
+            return false;
+        }
+    for (uint32_t i = 0; i < d->n_materials; i++)
+        if (d->materials[i].texture >= int32_t(d->n_textures)) {
+            setErr("rtx_scene_create: material %u has texture %d of %u", i, d->materials[i].texture, d->n_textures);
+            return false;
+        }
+    if (d->envmap.texture >= int32_t(d->n_textures)) {
+        setErr("rtx_scene_create: environment map texture %d of %u", d->envmap.texture, d->n_textures);
+        return false;
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rtx_texture& t = d->textures[i];
+        if (t.levels < 1 || t.levels > RTX_MAX_MIP_LEVELS) {
+            setErr("rtx_scene_create: texture %u has %d levels", i, t.levels);
+            return false;
+        }
+        for (int l = 0; l < t.levels; l++)
+            if (uint64_t(t.offset[l]) + t.count[l] > d->n_texels || t.width[l] < 0 || t.height[l] < 0) {
+                setErr("rtx_scene_create: texture %u level %d outside the texel pool", i, l);
+                return false;
+            }
+    }
+    if (d->n_env_bins && !d->env_bins) {
+        setErr("rtx_scene_create: %u environment bins but NULL array", d->n_env_bins);
+        return false;
+    }
+    for (uint32_t i = 0; i < d->n_lights; i++)
+        if (d->lights[i].type < RTX_LIGHT_POINT || d->lights[i].type > RTX_LIGHT_PARALLELOGRAM) {
+            setErr("rtx_scene_create: light %u has unknown type %d", i, d->lights[i].type);
+            return false;
+        }
+
+    return true;
+}
+
+// Materials, textures, lights, spheres and the environment map of a scene: uploaded as they are.
+int uploadShading(rtx_scene* s, const rtx_scene_desc* d)
+{
+    int rc = upload(s, d->materials, d->n_materials, &s->d.mats);
+    rc = rc ? rc : upload(s, d->textures, d->n_textures, &s->d.textures);
+    rc = rc ? rc : upload(s, d->texels, size_t(d->n_texels) * 3, &s->d.texels);
+    rc = rc ? rc : upload(s, d->lights, d->n_lights, &s->d.lights);
+    rc = rc ? rc : upload(s, d->spheres, d->n_spheres, &s->d.spheres);
+    const float* bins = nullptr;
+    rc = rc ? rc : upload(s, d->env_bins, size_t(d->n_env_bins) * 4, &bins);
+    s->d.envBins = reinterpret_cast<const float4*>(bins);
+    s->d.env = d->envmap;
+    s->d.nLights = int32_t(d->n_lights);
+    s->d.nEnvBins = int32_t(d->n_env_bins);
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        s->hasAreaLight = s->hasAreaLight || d->lights[i].type != RTX_LIGHT_POINT;
+        s->lightTypes.push_back(d->lights[i].type);
+    }
+    s->d.nSpheres = int32_t(d->n_spheres);
+    s->d.nMaterials = int32_t(d->n_materials);
+    return rc;
+}
+
 } // namespace
 
 // =================================================================== ABI ====
@@ -3423,51 +3502,8 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
                 }
         }
     }
-    for (uint32_t i = 0; i < d->n_tris; i++) {
-        if (d->tris[i].material < 0 || uint32_t(d->tris[i].material) >= d->n_materials) {
-            setErr("rtx_scene_create: triangle %u has material %d of %u", i, d->tris[i].material, d->n_materials);
-            return nullptr;
-        }
-        if (d->tris[i].id < 0 || uint32_t(d->tris[i].id) >= d->n_tris) {
-            setErr("rtx_scene_create: triangle %u has id %d of %u", i, d->tris[i].id, d->n_tris);
-            return nullptr;
-        }
-    }
-    for (uint32_t i = 0; i < d->n_spheres; i++)
-        if (d->spheres[i].material < 0 || uint32_t(d->spheres[i].material) >= d->n_materials) {
-            setErr("rtx_scene_create: sphere %u has material %d of %u", i, d->spheres[i].material, d->n_materials);
-            return nullptr;
-        }
-    for (uint32_t i = 0; i < d->n_materials; i++)
-        if (d->materials[i].texture >= int32_t(d->n_textures)) {
-            setErr("rtx_scene_create: material %u has texture %d of %u", i, d->materials[i].texture, d->n_textures);
-            return nullptr;
-        }
-    if (d->envmap.texture >= int32_t(d->n_textures)) {
-        setErr("rtx_scene_create: environment map texture %d of %u", d->envmap.texture, d->n_textures);
+    if (!shadingInputsOk(d))
         return nullptr;
-    }
-    for (uint32_t i = 0; i < d->n_textures; i++) {
-        const rtx_texture& t = d->textures[i];
-        if (t.levels < 1 || t.levels > RTX_MAX_MIP_LEVELS) {
-            setErr("rtx_scene_create: texture %u has %d levels", i, t.levels);
-            return nullptr;
-        }
-        for (int l = 0; l < t.levels; l++)
-            if (uint64_t(t.offset[l]) + t.count[l] > d->n_texels || t.width[l] < 0 || t.height[l] < 0) {
-                setErr("rtx_scene_create: texture %u level %d outside the texel pool", i, l);
-                return nullptr;
-            }
-    }
-    if (d->n_env_bins && !d->env_bins) {
-        setErr("rtx_scene_create: %u environment bins but NULL array", d->n_env_bins);
-        return nullptr;
-    }
-    for (uint32_t i = 0; i < d->n_lights; i++)
-        if (d->lights[i].type < RTX_LIGHT_POINT || d->lights[i].type > RTX_LIGHT_PARALLELOGRAM) {
-            setErr("rtx_scene_create: light %u has unknown type %d", i, d->lights[i].type);
-            return nullptr;
-        }
 
     rtx_scene* s = new (std::nothrow) rtx_scene;
     if (!s) {
@@ -3476,6 +3512,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     }
     s->device = g_ctx->device;
     s->numLevels = std::max(d->num_levels, walkedLevels); // (never less than the tree really has: it sizes the traversal stack)
+    s->numLeaves = d->num_leaves;
     // A shallow cut through the tree, level by level while it stays within
     // kMaxCutBoxes: its boxes together hold every triangle.
     if (d->root_ref >= 0) {
@@ -3667,14 +3704,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     tris = reinterpret_cast<const rtx_tri*>(nodes ? nodes + d->n_nodes : nullptr);
     rc = rc ? rc : upload(s, d->tri_attrs, d->n_tris, &attrs);
     rc = rc ? rc : upload(s, idOrder.data(), idOrder.size(), &s->d.idOrder);
-    rc = rc ? rc : upload(s, d->materials, d->n_materials, &s->d.mats);
-    rc = rc ? rc : upload(s, d->textures, d->n_textures, &s->d.textures);
-    rc = rc ? rc : upload(s, d->texels, size_t(d->n_texels) * 3, &s->d.texels);
-    rc = rc ? rc : upload(s, d->lights, d->n_lights, &s->d.lights);
-    rc = rc ? rc : upload(s, d->spheres, d->n_spheres, &s->d.spheres);
-    const float* bins = nullptr;
-    rc = rc ? rc : upload(s, d->env_bins, size_t(d->n_env_bins) * 4, &bins);
-    s->d.envBins = reinterpret_cast<const float4*>(bins);
+    rc = rc ? rc : uploadShading(s, d);
     if (rc) {
         rtx_scene_destroy(s);
         return nullptr;
@@ -3687,21 +3717,273 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     s->d.waveRoot = d->root_ref >= 0 ? 0 : (emptyTree ? kEmptyRoot : ~int32_t(uint32_t(~d->root_ref)));
     s->d.waveNodes = reinterpret_cast<const float4*>(dWaveNodes);
     s->d.waveTris = reinterpret_cast<const float4*>(dWaveTris);
-    s->d.env = d->envmap;
     s->d.nNodes = int32_t(d->n_nodes);
     s->d.nTris = int32_t(d->n_tris);
-    s->d.nLights = int32_t(d->n_lights);
-    s->d.nEnvBins = int32_t(d->n_env_bins);
-    for (uint32_t i = 0; i < d->n_lights; i++) {
-        s->hasAreaLight = s->hasAreaLight || d->lights[i].type != RTX_LIGHT_POINT;
-        s->lightTypes.push_back(d->lights[i].type);
-    }
-    s->d.nSpheres = int32_t(d->n_spheres);
-    s->d.nMaterials = int32_t(d->n_materials);
     s->d.rootRef = (d->root_ref < 0 && d->root_ref != kEmptyRoot) ? ~int32_t(d->n_nodes + uint32_t(~d->root_ref)) : d->root_ref;
     memcpy(s->d.rootLo, d->root_lo, sizeof(s->d.rootLo));
     memcpy(s->d.rootHi, d->root_hi, sizeof(s->d.rootHi));
     return s;
+}
+
+// The scene with its acceleration structure built on the GPU (see rtx_build.hpp).  d->tris and
+// d->tri_attrs hold the triangles in id order (record i has id i); d->nodes / root_* are ignored.
+rtx_scene* rtx_scene_build_device(const rtx_scene_desc* d)
+{
+    using namespace rtxbuild;
+    if (checkCtx(nullptr))
+        return nullptr;
+    if (!d || (d->n_tris && (!d->tris || !d->tri_attrs))) {
+        setErr("rtx_scene_build_device: NULL description or triangle arrays");
+        return nullptr;
+    }
+    if (d->n_tris > (1u << 30)) {
+        setErr("rtx_scene_build_device: scene too large");
+        return nullptr;
+    }
+    {
+        const struct { const void* p; uint64_t n; const char* what; } arrays[] = { { d->materials, d->n_materials, "materials" }, { d->textures, d->n_textures, "textures" },
+            { d->texels, d->n_texels, "texels" }, { d->lights, d->n_lights, "lights" }, { d->spheres, d->n_spheres, "spheres" } };
+        for (const auto& a : arrays)
+            if (a.n && !a.p) {
+                setErr("rtx_scene_build_device: %llu %s but a NULL array", (unsigned long long)a.n, a.what);
+                return nullptr;
+            }
+    }
+    if (!shadingInputsOk(d))
+        return nullptr;
+    for (uint32_t i = 0; i < d->n_tris; i++)
+        if (uint32_t(d->tris[i].id) != i) {
+            setErr("rtx_scene_build_device: triangle record %u carries id %d (the records must come in id order)", i, d->tris[i].id);
+            return nullptr;
+        }
+    const uint32_t n = d->n_tris;
+    if (n <= uint32_t(kLeafMax)) {
+        // too few triangles for a tree: one leaf (or none), through the ordinary upload
+        rtx_scene_desc one = *d;
+        std::vector<rtx_tri> tris(d->tris, d->tris + n);
+        float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+        for (uint32_t i = 0; i < n; i++) {
+            tris[i].flags = i + 1 == n ? RTX_TRI_LAST_IN_LEAF : 0;
+            for (int a = 0; a < 3; a++) {
+                const float mn = std::min({ tris[i].v0[a], tris[i].v1[a], tris[i].v2[a] }), mx = std::max({ tris[i].v0[a], tris[i].v1[a], tris[i].v2[a] });
+                lo[a] = i ? std::min(lo[a], mn) : mn;
+                hi[a] = i ? std::max(hi[a], mx) : mx;
+            }
+        }
+        one.tris = tris.data();
+        one.nodes = nullptr;
+        one.n_nodes = 0;
+        one.root_ref = n ? ~0 : INT32_MIN;
+        one.root_cnt = int32_t(n);
+        std::memcpy(one.root_lo, lo, 12);
+        std::memcpy(one.root_hi, hi, 12);
+        one.num_levels = n ? 1 : 0;
+        one.num_leaves = n ? 1 : 0;
+        return rtx_scene_create(&one);
+    }
+    DeviceCtx* c = g_ctx;
+    std::lock_guard<std::mutex> launchLock(c->launch);
+    hipStream_t stream = c->stream;
+    std::vector<void*> temps;
+    auto release = [&] {
+        (void)hipStreamSynchronize(stream);
+        for (void* t : temps)
+            (void)hipFree(t);
+        temps.clear();
+    };
+    bool ok = true;
+    auto grab = [&](size_t bytes) -> void* {
+        void* ptr = nullptr;
+        if (ok && hipMalloc(&ptr, std::max<size_t>(bytes, 16)) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+            ptr = nullptr;
+        }
+        if (ptr)
+            temps.push_back(ptr);
+        return ptr;
+    };
+    BuildBuffers B {};
+    B.n = n;
+    // A linear BVH grows deep chains where triangles crowd (equal Morton codes: up to 32 more
+    // levels, one per bit of the position that breaks the tie).  From this depth on, subtrees of up
+    // to kDeepLeafMax triangles are leaves, which keeps the tree within the traversal's 64-entry
+    // stack.  (Taking such leaves from a shallower depth, to fit a smaller stack, was measured and
+    // dropped: on the headline scene leaves of up to 64 triangles from level 14 on cost 1.65 ms a
+    // frame against 1.15 ms on the full tree.)
+    B.deepFrom = 56;
+    if (const char* e = getenv("RTX_BUILD_DEEP_FROM")) // diagnostic
+        B.deepFrom = uint32_t(std::max(1, atoi(e)));
+    rtx_tri* dTris = static_cast<rtx_tri*>(grab(size_t(n) * sizeof(rtx_tri)));
+    rtx_tri_attr* dAttrs = static_cast<rtx_tri_attr*>(grab(size_t(n) * sizeof(rtx_tri_attr)));
+    B.tris = dTris;
+    B.attrs = dAttrs;
+    B.primLo = static_cast<float*>(grab(size_t(n) * 12));
+    B.primHi = static_cast<float*>(grab(size_t(n) * 12));
+    B.keys = static_cast<uint64_t*>(grab(size_t(n) * 8));
+    B.keysSorted = static_cast<uint64_t*>(grab(size_t(n) * 8));
+    B.order = static_cast<uint32_t*>(grab(size_t(n) * 4));
+    B.orderSorted = static_cast<uint32_t*>(grab(size_t(n) * 4));
+    B.left = static_cast<int32_t*>(grab(size_t(n) * 4));
+    B.right = static_cast<int32_t*>(grab(size_t(n) * 4));
+    B.first = static_cast<uint32_t*>(grab(size_t(n) * 4));
+    B.last = static_cast<uint32_t*>(grab(size_t(n) * 4));
+    B.parent = static_cast<int32_t*>(grab(size_t(n) * 4));
+    B.leafParent = static_cast<int32_t*>(grab(size_t(n) * 4));
+    B.arrived = static_cast<uint32_t*>(grab(size_t(n) * 4));
+    B.nodeLo = static_cast<float*>(grab(size_t(n) * 12));
+    B.nodeHi = static_cast<float*>(grab(size_t(n) * 12));
+    B.alive = static_cast<uint32_t*>(grab(size_t(n) * 4));
+    B.wide = static_cast<uint32_t*>(grab(size_t(n) * 4));
+    B.aliveIndex = static_cast<uint32_t*>(grab(size_t(n) * 4));
+    B.wideIndex = static_cast<uint32_t*>(grab(size_t(n) * 4));
+    B.scalars = static_cast<uint32_t*>(grab(64));
+    float* dCut = static_cast<float*>(grab((1 + size_t(kMaxCutBoxes) * 6) * sizeof(float)));
+    size_t sortBytes = 0, scanBytes = 0;
+    if (ok) {
+        ok = rocprim::radix_sort_pairs(nullptr, sortBytes, B.keys, B.keysSorted, B.order, B.orderSorted, size_t(n), 0u, 63u, stream) == hipSuccess
+            && rocprim::exclusive_scan(nullptr, scanBytes, B.alive, B.aliveIndex, 0u, size_t(n - 1), rocprim::plus<uint32_t>(), stream) == hipSuccess;
+    }
+    void* dSortTemp = grab(std::max(sortBytes, scanBytes));
+    if (!ok) {
+        setErr("rtx_scene_build_device: out of device memory for %u triangles", n);
+        release();
+        return nullptr;
+    }
+    const uint32_t scalarInit[16] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const dim3 perTri((n + 255u) / 256u), perNode((n - 1 + 255u) / 256u), block(256);
+    const double tStart = nowMs();
+    hipError_t e = hipMemcpyAsync(dTris, d->tris, size_t(n) * sizeof(rtx_tri), hipMemcpyHostToDevice, stream);
+    e = e ? e : hipMemcpyAsync(dAttrs, d->tri_attrs, size_t(n) * sizeof(rtx_tri_attr), hipMemcpyHostToDevice, stream);
+    e = e ? e : hipMemcpyAsync(B.scalars, scalarInit, sizeof(scalarInit), hipMemcpyHostToDevice, stream);
+    e = e ? e : hipMemsetAsync(B.arrived, 0, size_t(n) * 4, stream);
+    e = e ? e : hipStreamSynchronize(stream);
+    const double tUploaded = nowMs();
+    if (!e) {
+        hipLaunchKernelGGL(primBoundsKernel, perTri, block, 0, stream, B);
+        hipLaunchKernelGGL(mortonKernel, perTri, block, 0, stream, B);
+        e = rocprim::radix_sort_pairs(dSortTemp, sortBytes, B.keys, B.keysSorted, B.order, B.orderSorted, size_t(n), 0u, 63u, stream);
+    }
+    if (!e) {
+        hipLaunchKernelGGL(hierarchyKernel, perNode, block, 0, stream, B);
+        hipLaunchKernelGGL(refitKernel, perTri, block, 0, stream, B);
+        hipLaunchKernelGGL(markKernel, perNode, block, 0, stream, B);
+        e = rocprim::exclusive_scan(dSortTemp, scanBytes, B.alive, B.aliveIndex, 0u, size_t(n - 1), rocprim::plus<uint32_t>(), stream);
+        e = e ? e : rocprim::exclusive_scan(dSortTemp, scanBytes, B.wide, B.wideIndex, 0u, size_t(n - 1), rocprim::plus<uint32_t>(), stream);
+    }
+    uint32_t scalars[16] = {}, tail[4] = {};
+    e = e ? e : hipMemcpyAsync(scalars, B.scalars, sizeof(scalars), hipMemcpyDeviceToHost, stream);
+    e = e ? e : hipMemcpyAsync(&tail[0], B.aliveIndex + (n - 2), 4, hipMemcpyDeviceToHost, stream);
+    e = e ? e : hipMemcpyAsync(&tail[1], B.alive + (n - 2), 4, hipMemcpyDeviceToHost, stream);
+    e = e ? e : hipMemcpyAsync(&tail[2], B.wideIndex + (n - 2), 4, hipMemcpyDeviceToHost, stream);
+    e = e ? e : hipMemcpyAsync(&tail[3], B.wide + (n - 2), 4, hipMemcpyDeviceToHost, stream);
+    e = e ? e : hipStreamSynchronize(stream);
+    e = e ? e : hipGetLastError();
+    if (e) {
+        setErr("rtx_scene_build_device: %s", hipGetErrorString(e));
+        release();
+        return nullptr;
+    }
+    if (scalars[6]) {
+        setErr("rtx_scene_build_device: a triangle has a vertex position that is not finite");
+        release();
+        return nullptr;
+    }
+    const uint32_t nNodes = tail[0] + tail[1], nWide = tail[2] + tail[3];
+    const int levels = int(scalars[7]) + 2; // inner nodes on the longest path from the root, plus the leaf
+    if (pickStack(levels) < 0) {
+        setErr("rtx_scene_build_device: the tree has %d levels; the device traversal stack holds 64 (many triangles share one place: use the host builder)", levels);
+        release();
+        return nullptr;
+    }
+    rtx_scene* s = new (std::nothrow) rtx_scene;
+    if (!s) {
+        setErr("out of host memory");
+        release();
+        return nullptr;
+    }
+    s->device = c->device;
+    s->numLevels = levels;
+    s->numLeaves = int(scalars[8]);
+    Outputs O {};
+    O.nNodes = nNodes;
+    O.nWide = nWide;
+    auto keep = [&](size_t bytes) -> void* {
+        void* ptr = nullptr;
+        if (ok && hipMalloc(&ptr, std::max<size_t>(bytes, 16)) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+            ptr = nullptr;
+        }
+        if (ptr)
+            s->buffers[s->nBuffers++] = ptr;
+        return ptr;
+    };
+    O.records = static_cast<float4*>(keep((size_t(nNodes) + n) * 64));
+    O.waveNodes = static_cast<float4*>(keep(size_t(nWide) * 8 * 128));
+    O.waveTris = static_cast<float4*>(keep(size_t(n) * 96));
+    O.attrs = static_cast<rtx_tri_attr*>(keep(size_t(n) * sizeof(rtx_tri_attr)));
+    O.idOrder = static_cast<int32_t*>(keep(size_t(n) * 4));
+    float rootBox[6] = {}, cut[1 + kMaxCutBoxes * 6] = {};
+    if (ok) {
+        hipLaunchKernelGGL(triangleRecordsKernel, perTri, block, 0, stream, B, O);
+        hipLaunchKernelGGL(nodeRecordsKernel, perNode, block, 0, stream, B, O);
+        hipLaunchKernelGGL(wideRecordsKernel, perNode, block, 0, stream, B, O);
+        hipLaunchKernelGGL(cutKernel, dim3(1), dim3(1), 0, stream, B, kMaxCutBoxes, dCut);
+        e = hipMemcpyAsync(rootBox, B.nodeLo, 12, hipMemcpyDeviceToHost, stream);
+        e = e ? e : hipMemcpyAsync(rootBox + 3, B.nodeHi, 12, hipMemcpyDeviceToHost, stream);
+        e = e ? e : hipMemcpyAsync(cut, dCut, sizeof(cut), hipMemcpyDeviceToHost, stream);
+        e = e ? e : hipStreamSynchronize(stream);
+        e = e ? e : hipGetLastError();
+        ok = e == hipSuccess;
+    }
+    release();
+    s->uploadMs = float(tUploaded - tStart);
+    s->buildMs = float(nowMs() - tUploaded); // (ends with the records in place and the temporary buffers freed)
+    if (ok && uploadShading(s, d) != RTX_OK)
+        ok = false;
+    if (!ok) {
+        if (e)
+            setErr("rtx_scene_build_device: %s", hipGetErrorString(e));
+        else if (!g_err[0])
+            setErr("rtx_scene_build_device: out of device memory");
+        rtx_scene_destroy(s);
+        return nullptr;
+    }
+    for (int k = 0; k < int(cut[0]) && k < kMaxCutBoxes; k++) {
+        std::array<float, 6> box;
+        std::memcpy(box.data(), cut + 1 + k * 6, sizeof(float) * 6);
+        s->cutBoxes.push_back(box);
+    }
+    s->d.nodes = O.records;
+    s->d.tris = O.records + size_t(nNodes) * 4;
+    s->d.attrs = reinterpret_cast<const float4*>(O.attrs);
+    s->d.idOrder = O.idOrder;
+    s->d.boxesNested = 1; // every box is the union of what lies below it
+    s->d.nWaveNodes = int32_t(nWide);
+    s->d.waveRoot = 0;
+    s->d.waveNodes = O.waveNodes;
+    s->d.waveTris = O.waveTris;
+    s->d.nNodes = int32_t(nNodes);
+    s->d.nTris = int32_t(n);
+    s->d.rootRef = 0;
+    std::memcpy(s->d.rootLo, rootBox, 12);
+    std::memcpy(s->d.rootHi, rootBox + 3, 12);
+    return s;
+}
+
+// numLevels / numLeaves of the scene's tree as uploaded or built (BvhInterface::numLevels, numLeaves)
+int rtx_scene_tree_info(const rtx_scene* scene, rtx_tree_info* info)
+{
+    if (!scene || !info) {
+        setErr("rtx_scene_tree_info: NULL argument");
+        return RTX_ERR_INVALID;
+    }
+    info->levels = scene->numLevels;
+    info->leaves = scene->numLeaves;
+    info->upload_ms = scene->uploadMs;
+    info->build_ms = scene->buildMs;
+    return RTX_OK;
 }
 
 void rtx_scene_retain(rtx_scene* s)

@@ -182,12 +182,18 @@ def flatten(scene: SceneData, features: abi.Features) -> FlatScene:
 class GpuEngine:
     kind = "hip"
 
-    def __init__(self, scene: SceneData, features: abi.Features, device=None):
+    def __init__(self, scene: SceneData, features: abi.Features, device=None, device_build=False):
+        """device_build: the tree is built on the GPU (rtx_scene_build_device) instead of by the
+        host's restatement of the reference's builder."""
         lib = host_lib()
         if device is not None:
             _check(lib.rtxh_select_device(int(device)), "select_device")
         self.scene = HostScene(scene)
-        self.b = lib.rtxh_bvh_create(vp(self.scene.h), C.byref(features))
+        lib.rtxh_set_device_build(1 if device_build else 0)
+        try:
+            self.b = lib.rtxh_bvh_create(vp(self.scene.h), C.byref(features))
+        finally:
+            lib.rtxh_set_device_build(0)
         if not self.b:
             msg = lib.rtxh_last_error().decode()
             self.scene.close()
@@ -205,6 +211,12 @@ class GpuEngine:
 
     def leaves(self):
         return host_lib().rtxh_bvh_leaves(vp(self.b))
+
+    def tree_info(self):
+        """levels, leaves and, for a tree built on the GPU, the milliseconds its upload and build took."""
+        out = (C.c_float * 4)()
+        _check(host_lib().rtxh_bvh_tree_info(vp(self.b), out), "tree_info")
+        return dict(levels=int(out[0]), leaves=int(out[1]), upload_ms=float(out[2]), build_ms=float(out[3]))
 
     def flat(self):
         return FlatScene(host_lib().rtxh_bvh_flat(vp(self.b)), False)

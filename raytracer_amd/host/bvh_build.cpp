@@ -307,7 +307,7 @@ void radianceBins(const Image& img, float lx, float ly, float ux, float uy, floa
 
 } // namespace
 
-FlatScene flattenScene(const Scene& scene, const Features& features)
+FlatScene flattenScene(const Scene& scene, const Features& features, bool buildTree)
 {
     FlatScene out;
     std::map<const Image*, int> texIndex;
@@ -392,6 +392,24 @@ FlatScene flattenScene(const Scene& scene, const Features& features)
     const size_t n = prims.size();
     if (n == 0)
         return out; // empty tree (e.g. the Spheres scene): rootRef stays INT32_MIN
+    if (!buildTree) {
+        // the triangle records as they are, in id order, for the device's builder
+        Builder b { scene, prims, out, -1, false };
+        out.tris.resize(n);
+        out.attrs.resize(n);
+        const size_t nThreads = n >= Builder::kParallelAbove ? std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16) : 1;
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < nThreads; w++)
+            pool.emplace_back([&, w] {
+                for (size_t k = n * w / nThreads; k < n * (w + 1) / nThreads; k++)
+                    b.writeTriangle(k, k, false);
+            });
+        for (size_t k = 0; k < n / nThreads; k++)
+            b.writeTriangle(k, k, false);
+        for (std::thread& t : pool)
+            t.join();
+        return out;
+    }
     std::vector<size_t> idx(n);
     for (size_t i = 0; i < n; i++)
         idx[i] = i;

@@ -35,6 +35,9 @@ struct FlatScene {
 
 // Build the tree over scene.meshes and gather materials, textures (with their
 // mip chains, src/main.cpp:745-771), lights, spheres and the environment map.
-FlatScene flattenScene(const Scene& scene, const Features& features);
+// With buildTree == false no tree is made: tris / attrs come in meshTrianglePairs (id) order
+// and rootRef stays empty, which is what rtx_scene_build_device takes to build its own tree
+// on the GPU.
+FlatScene flattenScene(const Scene& scene, const Features& features, bool buildTree = true);
 
 } // namespace rt

@@ -89,6 +89,9 @@ int rtxh_select_device(int device)
     return guarded([&] { selectDevice(device); });
 }
 
+// Where the next BvhInterface builds its tree: 0 on the host (the reference's builder), 1 on the GPU.
+void rtxh_set_device_build(int on) { buildTreeOnDevice = on != 0; }
+
 void* rtxh_scene_create() { return new HostScene; }
 void rtxh_scene_free(void* p) { delete static_cast<HostScene*>(p); }
 
@@ -269,6 +272,14 @@ void* rtxh_bvh_create(void* p, const rtx_features* f)
 void rtxh_bvh_free(void* b) { delete static_cast<BvhInterface*>(b); }
 int rtxh_bvh_levels(const void* b) { return static_cast<const BvhInterface*>(b)->numLevels(); }
 int rtxh_bvh_leaves(const void* b) { return static_cast<const BvhInterface*>(b)->numLeaves(); }
+// out: levels, leaves, upload ms, build ms (the last two only for a tree built on the GPU)
+int rtxh_bvh_tree_info(const void* b, float* out)
+{
+    rtx_tree_info info {};
+    const int rc = rtx_scene_tree_info(static_cast<const BvhInterface*>(b)->deviceScene(), &info);
+    out[0] = float(info.levels), out[1] = float(info.leaves), out[2] = info.upload_ms, out[3] = info.build_ms;
+    return rc;
+}
 const void* rtxh_bvh_flat(const void* b) { return &static_cast<const BvhInterface*>(b)->flat(); }
 const void* rtxh_bvh_device_scene(const void* b) { return static_cast<const BvhInterface*>(b)->deviceScene(); }
 

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -56,6 +57,8 @@ rtx_features toDeviceFeatures(const Features& f)
     return o;
 }
 
+bool buildTreeOnDevice = false;
+
 // ------------------------------------------------------------ BvhInterface --
 BvhInterface::BvhInterface(Scene* pScene, const Features& features)
     : m_pScene(pScene)
@@ -64,11 +67,24 @@ BvhInterface::BvhInterface(Scene* pScene, const Features& features)
     if (!pScene)
         throw RtError("BvhInterface: null scene");
     ensureDevice();
-    m_flat = std::make_shared<FlatScene>(flattenScene(*pScene, features));
+    const char* env = std::getenv("RTX_DEVICE_BUILD");
+    const bool onDevice = buildTreeOnDevice || (env && env[0] == '1');
+    m_flat = std::make_shared<FlatScene>(flattenScene(*pScene, features, !onDevice));
     const rtx_scene_desc d = m_flat->desc();
-    m_scene = rtx_scene_create(&d);
+    m_scene = onDevice ? rtx_scene_build_device(&d) : rtx_scene_create(&d);
     if (!m_scene)
-        fail("rtx_scene_create");
+        fail(onDevice ? "rtx_scene_build_device" : "rtx_scene_create");
+    if (onDevice) {
+        // numLevels / numLeaves are the built tree's; the triangle records are not needed again
+        rtx_tree_info info {};
+        rtx_scene_tree_info(m_scene, &info);
+        m_flat->numLevels = info.levels;
+        m_flat->numLeaves = info.leaves;
+        m_flat->tris.clear();
+        m_flat->tris.shrink_to_fit();
+        m_flat->attrs.clear();
+        m_flat->attrs.shrink_to_fit();
+    }
 }
 
 BvhInterface::BvhInterface(const BvhInterface& o)

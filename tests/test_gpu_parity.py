@@ -847,7 +847,23 @@ def test_ten_million_triangles_at_3840x2160(gpu_device):
     del acc, frames
     rays = engine.camera_rays(cam, W, H, step=40)
     got = gpu.intersect(rays, f)
+    small = make_params(960, 540, driver=abi.DRIVER_MRAYS, samples=4)
+    want_small = gpu.render(cam, f, small)
     gpu.close()
+    # the same scene with its tree built on the GPU: same hits, same frame
+    import time
+    t0 = time.perf_counter()
+    dev = GpuEngine(scene, f, device_build=True)
+    build_s = time.perf_counter() - t0
+    info = dev.tree_info()
+    print(f"device build of {scene.n_triangles} triangles incl. host records and upload: {build_s:.2f} s (upload {info['upload_ms']:.0f} ms, build on the GPU {info['build_ms']:.0f} ms), "
+          f"{dev.levels()} levels, {dev.leaves()} leaves")
+    assert info["build_ms"] < 500.0, "10 M triangles are built on the GPU in under half a second"
+    assert_hits_equal(dev.intersect(rays, f), got, "10 M triangles, tree built on the device vs on the host")
+    got_small = dev.render(cam, f, small)
+    differing = int(np.count_nonzero(np.any(got_small.view(np.uint32) != want_small.view(np.uint32), axis=-1)))
+    assert differing <= 4, f"{differing} pixels differ between the device-built and the host-built tree"
+    dev.close()
     orc = OracleEngine(scene, f)
     ties = assert_hits_equal(got, orc.intersect(rays, f), "10 M triangles, primary rays")
     orc.close()
@@ -873,3 +889,110 @@ def test_counting_kernel_builds_give_the_same_frames(gpu_device, monkeypatch):
         assert gpu.stats.rays == want_rays and gpu.stats.box_tests > 0 and gpu.stats.tri_tests > 0
         assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want)) and np.array_equal(np.isnan(got), np.isnan(want))
     gpu.close()
+
+
+# ---- the tree built on the GPU (rtx_scene_build_device) ---------------------------------
+@pytest.mark.parametrize("scene_name", [s for s in cases.SCENES if s != "spheres"])
+def test_device_built_tree_gives_the_reference_hits(gpu_device, golden_rays, scene_name):
+    """The linear BVH made on the GPU is not the reference's tree; the closest hit of a ray does not
+    depend on the tree, so hit flag, distance (bit for bit), triangle and attributes must be the
+    reference's on the committed ray batches (a different triangle only at an exact tie)."""
+    scene = cases.load_scene(scene_name)
+    rays = golden_rays[f"{scene_name}_rays"]
+    f = abi.features(accel_structure=1, bvh_sah_binning=1, normal_interp=1)
+    gpu = GpuEngine(scene, f, device_build=True)
+    got = gpu.intersect(rays, f)
+    assert gpu.levels() >= 1 and gpu.leaves() >= 1
+    gpu.close()
+    want = golden_rays[f"{scene_name}_interp_hits"]
+    assert_hits_equal(_settle_true_ties(scene, rays, got, want), want, f"{scene_name}, tree built on the device, vs reference")
+
+
+def _settle_true_ties(scene, rays, got, want):
+    """Where another tree reports another triangle at the very same distance, the hit point must lie
+    on that triangle too (a ray through an edge two triangles share): such rays then count as equal."""
+    tris = np.concatenate([m.vertices[m.triangles.astype(np.int64), :3] for m in scene.meshes]).astype(np.float64)
+    out = got.copy()
+    for i in np.flatnonzero((got["tri"] != want["tri"]) & (got["hit"] != 0) & (want["hit"] != 0) & (got["tri"] >= 0)):
+        if got["t"][i].view(np.uint32) != want["t"][i].view(np.uint32):
+            continue
+        p = rays["origin"][i].astype(np.float64) + float(got["t"][i]) * rays["direction"][i].astype(np.float64)
+        a, b, c = tris[got["tri"][i]]
+        n = np.cross(b - a, c - a)
+        n /= np.linalg.norm(n)
+        inside = all(np.dot(n, np.cross(q - r, p - r)) >= -1e-5 for r, q in ((a, b), (b, c), (c, a)))
+        if abs(np.dot(n, p - a)) < 1e-5 and inside:
+            for k in ("tri", "normal", "bary", "uv", "material"):
+                out[k][i] = want[k][i]
+    return out
+
+
+@pytest.mark.parametrize("name", ["cfg1_cornell", "monkey_mrays4", "teapot_mrays16", "monkey_dof5", "transparency_cg3", "monkey_blur3",
+                                  "cornell_area_glossy_d4", "cube_tex_trilinear", "monkey_env_cylindrical_bilinear", "spheres", "cornell_bruteforce"])
+def test_device_built_tree_gives_the_reference_frames(gpu_device, golden_images, name):
+    case = cases.CASES_BY_NAME[name]
+    scene, f, cam, rp = case.build()
+    gpu = GpuEngine(scene, f, device_build=True)
+    got = gpu.render(cam, f, rp)
+    counts = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
+    gpu.close()
+    assert_images_close(got, golden_images[name], name + ", tree built on the device, vs reference", max(RGB_TOL, case.tol))
+    host = GpuEngine(scene, f)
+    host.render(cam, f, rp)
+    assert counts == (host.stats.rays_primary, host.stats.rays_shadow, host.stats.rays_bounce)
+    host.close()
+
+
+def test_device_build_of_the_headline_scene_and_of_degenerate_inputs(gpu_device):
+    """81 920 triangles: the frame is the host-built tree's (the lean kernel's wave-shared walk over
+    the four-wide nodes included), determinism of the build, and inputs a builder must survive:
+    many triangles at one place (equal Morton codes), a degenerate triangle, four triangles or fewer."""
+    import time
+    scene = dragon_scene()
+    f = abi.features(**cases.BASE)
+    cam = make_camera()
+    rp = make_params(480, 270, driver=abi.DRIVER_MRAYS, samples=4)
+    host = GpuEngine(scene, f)
+    want = host.render(cam, f, rp)
+    want_counts = (host.stats.rays_primary, host.stats.rays_shadow)
+    host.close()
+    t0 = time.perf_counter()
+    dev = GpuEngine(scene, f, device_build=True)
+    build_s = time.perf_counter() - t0
+    got = dev.render(cam, f, rp)
+    assert (dev.stats.rays_primary, dev.stats.rays_shadow) == want_counts
+    differing = int(np.count_nonzero(np.any(_bits(got) != _bits(want), axis=-1)))
+    assert differing <= 2, f"{differing} pixels differ between the device-built and the host-built tree (exact ties are rare)"
+    again = GpuEngine(scene, f, device_build=True)
+    assert np.array_equal(_bits(again.render(cam, f, rp)), _bits(got)) and (again.levels(), again.leaves()) == (dev.levels(), dev.leaves())
+    again.close()
+    print(f"device build of {scene.n_triangles} triangles incl. host records and upload: {build_s * 1e3:.1f} ms, {dev.levels()} levels, {dev.leaves()} leaves")
+    dev.close()
+    # 300 copies of one triangle + a degenerate one + a few others
+    base = cases.load_scene("cube")
+    m = base.meshes[0]
+    tris = np.concatenate([np.repeat(m.triangles[:1], 300, axis=0), m.triangles, np.array([[0, 0, 1]], np.uint32)])
+    crowded = cases.load_scene("cube")
+    crowded.meshes[0] = type(m)(m.vertices, tris, m.material)
+    orc = OracleEngine(crowded, f)
+    rays = primary_rays(cam, 24, 24)
+    dev = GpuEngine(crowded, f, device_build=True)
+    assert_hits_equal(_same_triangle_ties(dev.intersect(rays, f), orc.intersect(rays, f)), orc.intersect(rays, f), "crowded scene")
+    dev.close()
+    orc.close()
+    for keep in (1, 4):
+        small = cases.load_scene("cube")
+        small.meshes[0] = type(m)(m.vertices, m.triangles[:keep], m.material)
+        dev, orc = GpuEngine(small, f, device_build=True), OracleEngine(small, f)
+        assert_hits_equal(dev.intersect(rays, f), orc.intersect(rays, f), f"{keep} triangles")
+        dev.close()
+        orc.close()
+
+
+def _same_triangle_ties(got, want):
+    """300 copies of one triangle tie at every hit: which copy wins is the visiting order's
+    choice, so the copies' ids are read as one."""
+    got = got.copy()
+    tie = (got["tri"] != want["tri"]) & (got["tri"] < 300) & (want["tri"] < 300) & (got["tri"] >= 0) & (want["tri"] >= 0)
+    got["tri"][tie] = want["tri"][tie]
+    return got
