@@ -29,13 +29,16 @@ raytracer_amd/librtx_host.so: $(HOST_SRC) $(HOST_HDR) raytracer_amd/librtx_hip.s
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -Lraytracer_amd -lrtx_hip -lz -Wl,-rpath,'$$ORIGIN'
 
 # headless example: OBJ in, BMP out, through the reference-shaped C++ API
-examples: raytracer_amd/render_obj
+examples: raytracer_amd/render_obj raytracer_amd/render_cli
 raytracer_amd/render_obj: examples/render_obj.cpp raytracer_amd/librtx_host.so
 	$(CXX) $(CXXFLAGS) -o $@ examples/render_obj.cpp -Lraytracer_amd -lrtx_host -lrtx_hip -Wl,-rpath,'$$ORIGIN'
+# the reference's command-line renderer (TOML configuration, one bitmap per camera) on the GPU path
+raytracer_amd/render_cli: examples/render_cli.cpp raytracer_amd/librtx_host.so
+	$(CXX) $(CXXFLAGS) -o $@ examples/render_cli.cpp -Lraytracer_amd -lrtx_host -lrtx_hip -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f raytracer_amd/librtx_hip.so raytracer_amd/librtx_host.so raytracer_amd/libvalu_peak.so
+	rm -f raytracer_amd/librtx_hip.so raytracer_amd/librtx_host.so raytracer_amd/libvalu_peak.so raytracer_amd/render_obj raytracer_amd/render_cli
 	$(MAKE) -C oracle clean

@@ -4,6 +4,7 @@
 // reference code; it only calls the reference's public functions.
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <filesystem>
 #include <limits>
@@ -22,6 +23,7 @@
 #include "bvh_interface.h"
 #undef private
 
+#include "config.h"
 #include "dof.h"
 // the radiance bins are a private member; the harness reads them for a known-answer test
 #define private public
@@ -94,6 +96,55 @@ Features toFeatures(const rtx_features* f)
 } // namespace
 
 extern "C" {
+
+// readConfigFile (src/config.cpp:201-382) flattened: out[0] command_line_rendering, [1..2] window size,
+// [3] the scene is a file (1) or a prebuilt scene (0), [4] the prebuilt scene's number, [5..10] the six
+// basic feature switches, [11..18] bloom, multiple rays, motion blur, depth of field, glossy, environment
+// map, bilinear, mipmap, [19..21] soft shadows, transparency, SAH binning, [22] number of cameras, then 8
+// numbers per camera, then the number of lights and 22 numbers per light; sceneName as src/main.cpp:534-543.
+int ref_read_config(const char* path, double* out, int capacity, char* sceneName, int nameCapacity)
+{
+    const Config c = readConfigFile(path);
+    std::vector<double> v;
+    v.push_back(c.cliRenderingEnabled);
+    v.push_back(c.windowSize.x);
+    v.push_back(c.windowSize.y);
+    const bool file = std::holds_alternative<std::filesystem::path>(c.scene);
+    v.push_back(file ? 1 : 0);
+    v.push_back(file ? -1 : int(std::get<SceneType>(c.scene)));
+    const Features& f = c.features;
+    for (bool b : { f.enableShading, f.enableRecursive, f.enableHardShadow, f.enableNormalInterp, f.enableTextureMapping, f.enableAccelStructure,
+             f.extra.enableBloomEffect, f.extra.enableMultipleRaysPerPixel, f.extra.enableMotionBlur, f.extra.enableDepthOfField, f.extra.enableGlossyReflection,
+             f.extra.enableEnvironmentMapping, f.extra.enableBilinearTextureFiltering, f.extra.enableMipmapTextureFiltering, f.enableSoftShadow,
+             f.extra.enableTransparency, f.extra.enableBvhSahBinning })
+        v.push_back(b ? 1 : 0);
+    v.push_back(double(c.cameras.size()));
+    for (const CameraConfig& cam : c.cameras)
+        for (float x : { cam.fieldOfView, cam.distanceFromLookAt, cam.lookAt.x, cam.lookAt.y, cam.lookAt.z, cam.rotation.x, cam.rotation.y, cam.rotation.z })
+            v.push_back(x);
+    v.push_back(double(c.lights.size()));
+    for (const auto& l : c.lights) {
+        double row[22] = {};
+        auto put = [&](int at, const glm::vec3& p) { row[at] = p.x, row[at + 1] = p.y, row[at + 2] = p.z; };
+        if (std::holds_alternative<PointLight>(l)) {
+            const auto& q = std::get<PointLight>(l);
+            row[0] = 0, put(1, q.position), put(10, q.color);
+        } else if (std::holds_alternative<SegmentLight>(l)) {
+            const auto& q = std::get<SegmentLight>(l);
+            row[0] = 1, put(1, q.endpoint0), put(4, q.endpoint1), put(10, q.color0), put(13, q.color1);
+        } else {
+            const auto& q = std::get<ParallelogramLight>(l);
+            row[0] = 2, put(1, q.v0), put(4, q.edge01), put(7, q.edge02), put(10, q.color0), put(13, q.color1), put(16, q.color2), put(19, q.color3);
+        }
+        v.insert(v.end(), row, row + 22);
+    }
+    if (int(v.size()) > capacity)
+        return -1;
+    std::copy(v.begin(), v.end(), out);
+    const std::string name = file ? std::get<std::filesystem::path>(c.scene).stem().string() : serialize(std::get<SceneType>(c.scene));
+    std::snprintf(sceneName, size_t(nameCapacity), "%s", name.c_str());
+    return int(v.size());
+}
 
 // ---------------------------------------------------------------- scenes ----
 void* ref_scene_prebuilt(int sceneType)

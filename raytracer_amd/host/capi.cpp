@@ -6,6 +6,7 @@
 #include <memory>
 #include <string>
 
+#include "config.h"
 #include "raytracer.h"
 #include "scene_io.h"
 
@@ -87,6 +88,67 @@ const char* rtxh_last_error() { return t_err.c_str(); }
 int rtxh_select_device(int device)
 {
     return guarded([&] { selectDevice(device); });
+}
+
+// readConfigFile flattened for tests: out[0] command_line_rendering, [1..2] window size, [3] the scene is a
+// file (1) or a prebuilt scene (0), [4] the prebuilt scene's number, [5..10] the six basic feature switches,
+// [11..18] bloom, multiple rays, motion blur, depth of field, glossy, environment map, bilinear, mipmap,
+// [19..21] soft shadows, transparency, SAH binning (extended keys), [22] number of cameras, then 8 numbers
+// per camera, then the number of lights and 22 numbers per light (kind, three points, four colours);
+// sceneName receives the scene's name as the output files carry it.  Returns the count of numbers written.
+int rtxh_read_config(const char* path, const char* dataDir, int extended, double* out, int capacity, char* sceneName, int nameCapacity)
+{
+    int written = -1;
+    const int rc = guarded([&] {
+        const Config c = readConfigFile(path, dataDir, extended != 0);
+        std::vector<double> v;
+        v.push_back(c.cliRenderingEnabled);
+        v.push_back(c.windowSize.x);
+        v.push_back(c.windowSize.y);
+        const bool file = std::holds_alternative<std::string>(c.scene);
+        v.push_back(file ? 1 : 0);
+        v.push_back(file ? -1 : int(std::get<SceneType>(c.scene)));
+        const Features& f = c.features;
+        for (bool b : { f.enableShading, f.enableRecursive, f.enableHardShadow, f.enableNormalInterp, f.enableTextureMapping, f.enableAccelStructure,
+                 f.extra.enableBloomEffect, f.extra.enableMultipleRaysPerPixel, f.extra.enableMotionBlur, f.extra.enableDepthOfField, f.extra.enableGlossyReflection,
+                 f.extra.enableEnvironmentMapping, f.extra.enableBilinearTextureFiltering, f.extra.enableMipmapTextureFiltering, f.enableSoftShadow,
+                 f.extra.enableTransparency, f.extra.enableBvhSahBinning })
+            v.push_back(b ? 1 : 0);
+        v.push_back(double(c.cameras.size()));
+        for (const CameraConfig& cam : c.cameras)
+            for (float x : { cam.fieldOfView, cam.distanceFromLookAt, cam.lookAt.x, cam.lookAt.y, cam.lookAt.z, cam.rotation.x, cam.rotation.y, cam.rotation.z })
+                v.push_back(x);
+        v.push_back(double(c.lights.size()));
+        for (const auto& l : c.lights) {
+            double row[22] = {};
+            auto put = [&](int at, const vec3& p) { row[at] = p.x, row[at + 1] = p.y, row[at + 2] = p.z; };
+            if (std::holds_alternative<PointLight>(l)) {
+                const auto& q = std::get<PointLight>(l);
+                row[0] = 0, put(1, q.position), put(10, q.color);
+            } else if (std::holds_alternative<SegmentLight>(l)) {
+                const auto& q = std::get<SegmentLight>(l);
+                row[0] = 1, put(1, q.endpoint0), put(4, q.endpoint1), put(10, q.color0), put(13, q.color1);
+            } else {
+                const auto& q = std::get<ParallelogramLight>(l);
+                row[0] = 2, put(1, q.v0), put(4, q.edge01), put(7, q.edge02), put(10, q.color0), put(13, q.color1), put(16, q.color2), put(19, q.color3);
+            }
+            v.insert(v.end(), row, row + 22);
+        }
+        if (int(v.size()) > capacity)
+            throw RtError("rtxh_read_config: output buffer too small");
+        std::copy(v.begin(), v.end(), out);
+        written = int(v.size());
+        std::string name = file ? std::get<std::string>(c.scene) : serialize(std::get<SceneType>(c.scene));
+        if (file) { // std::filesystem::path::stem
+            const size_t slash = name.find_last_of('/');
+            name = slash == std::string::npos ? name : name.substr(slash + 1);
+            const size_t dot = name.find_last_of('.');
+            if (dot != std::string::npos && dot > 0)
+                name = name.substr(0, dot);
+        }
+        std::snprintf(sceneName, size_t(nameCapacity), "%s", name.c_str());
+    });
+    return rc ? rc : written;
 }
 
 // Where the next BvhInterface builds its tree: 0 on the host (the reference's builder), 1 on the GPU.

@@ -16,6 +16,7 @@ Outputs (all data, no reference source):
     rays.npz            per scene: a ray batch and the reference's HitInfo for it
     images.npz          per image case: the reference's frame (fp32 RGB)
     shade.npz           getFinalColor on a batch of caller-supplied rays
+    config.npz          readConfigFile's result for the TOML files of toml/
     kat.npz             per-function known answers (slab, triangle, sphere,
                         barycentric, shading, reflection, textures, mip chain,
                         environment map, light sampling, glossy fan, RNG stream)
@@ -403,9 +404,31 @@ def make_kat():
     print("kat", len(out), "arrays")
 
 
+def make_config():
+    """What the reference's readConfigFile (src/config.cpp:201-382) makes of the TOML files of
+    tests/golden/toml/ (written for this build; the reference ships no configuration file)."""
+    import glob
+    import tempfile
+    lib = RefEngine.lib()
+    out = {}
+    for path in sorted(glob.glob(os.path.join(OUT, "toml", "*.toml"))):
+        name = os.path.splitext(os.path.basename(path))[0]
+        text = open(path).read().replace("@DATA@", os.path.join(OUT, "obj_scene"))
+        with tempfile.NamedTemporaryFile("w", suffix=".toml", delete=False) as fh:
+            fh.write(text)
+        values = (C.c_double * 4096)()
+        scene = C.create_string_buffer(256)
+        n = lib.ref_read_config(fh.name.encode(), values, 4096, scene, 256)
+        os.unlink(fh.name)
+        assert n > 0, path
+        out[name] = np.array(values[:n], np.float64)
+        out[name + "_scene"] = np.frombuffer(scene.value, np.uint8)
+    np.savez_compressed(os.path.join(OUT, "config.npz"), **out)
+
+
 if __name__ == "__main__":
     if not have_ref():
         sys.exit("oracle/_ref/libref.so is missing: run `make -C oracle ref` where /root/reference exists")
-    what = sys.argv[1:] or ["scenes", "bvh", "rays", "images", "shade", "kat", "obj"]
+    what = sys.argv[1:] or ["scenes", "bvh", "rays", "images", "shade", "kat", "obj", "config"]
     for w in what:
         globals()["make_" + w]()

@@ -391,6 +391,43 @@ def test_headless_example_renders_an_obj_to_a_bitmap(gpu_device, tmp_path):
     assert np.array_equal(rows[..., :3][..., ::-1], want) or np.array_equal(rows[..., :3], want)
 
 
+def test_command_line_renderer_from_a_configuration_file(gpu_device, tmp_path):
+    """examples/render_cli.cpp, the reference's command line (src/main.cpp:520-589): a TOML file names an
+    OBJ scene, lights, features and two cameras; each camera's bitmap holds the frame the oracle renders
+    for that camera with the driver the reference's router picks (here the jittered one, 64 samples)."""
+    import glob
+    import os
+    import subprocess
+    from raytracer_amd import engine
+    exe = os.path.join(os.path.dirname(engine.HIP_SO), "render_cli")
+    assert os.path.exists(exe), "raytracer_amd/render_cli not built (make examples)"
+    data = os.path.join(cases.GOLDEN, "obj_scene")
+    text = open(os.path.join(cases.GOLDEN, "toml", "file_scene.toml")).read().replace("@DATA@", data).replace('output_dir = "."', f'output_dir = "{tmp_path}/frames/deep"')
+    text += "\n[[cameras]]\nfield_of_view = 40.0\ndistance_from_look_at = 2.5\nlook_at = [0.1, 0.0, 0.0]\nrotation = [-30.0, 110.0, 0.0]\n"
+    (tmp_path / "job.toml").write_text(text)
+    r = subprocess.run([exe, str(tmp_path / "job.toml")], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr
+    assert "2 images rendered" in r.stdout
+    scene = engine.load_obj(os.path.join(data, "cube.obj"), normalize=False)
+    scene.lights = [abi.point_light((-1, 1, -1), (1, 1, 1))]
+    f = abi.features(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1)   # (the reader leaves SAH binning off)
+    orc = OracleEngine(scene, f)
+    for index, cam in enumerate((make_camera(), make_camera(fov_degrees=40.0, distance=2.5, look_at=(0.1, 0.0, 0.0), rotation_degrees=(-30.0, 110.0, 0.0)))):
+        files = glob.glob(str(tmp_path / "frames" / "deep" / f"cube_*_cam_{index}.bmp"))
+        assert len(files) == 1, files
+        raw = open(files[0], "rb").read()
+        assert raw[:2] == b"BM" and int.from_bytes(raw[18:22], "little") == 96 and abs(int.from_bytes(raw[22:26], "little", signed=True)) == 54
+        img = orc.render(cam, f, make_params(96, 54, driver=abi.DRIVER_MRAYS))
+        want = (np.clip(img, 0, 1) * 255).astype(np.uint8)
+        off = int.from_bytes(raw[10:14], "little")
+        px = np.frombuffer(raw[off:off + 96 * 54 * 4], np.uint8).reshape(54, 96, 4)
+        rows = px if int.from_bytes(raw[22:26], "little", signed=True) < 0 else px[::-1]
+        got = rows[..., :3][..., ::-1] if np.abs(rows[..., :3][..., ::-1].astype(int) - want).max() <= np.abs(rows[..., :3].astype(int) - want).max() else rows[..., :3]
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1, f"camera {index}"   # (8-bit truncation of values within 1e-3)
+        assert want.max() > 100
+    orc.close()
+
+
 def test_c_abi_rejects_bad_input(gpu_device):
     """Error behaviour of the C ABI: a negative status and a message, never a launch,
     for NULL arguments, unknown drivers, limits and inconsistent scene descriptions."""
