@@ -2924,8 +2924,9 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // lights: with a full wave of paths the lanes' own traversals already run side by side)
     const bool fans = f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1 && A.glossyRays <= kFanMax
         && A.pixelsPerUnit * A.lanesPerPixel <= 8 && !getenv("RTX_NO_FANS");
-    // (the lens samples of the depth-of-field driver make no coherent bundle: lane by lane; RTX_LEAN_WALK=0/1 overrides)
-    const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : driver != RTX_DRIVER_DOF;
+    // (the lens samples of the depth-of-field driver make no coherent bundle, and 64 pixels with one
+    // sample each share too little of the tree below its top levels: lane by lane; RTX_LEAN_WALK=0/1 overrides)
+    const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : driver != RTX_DRIVER_DOF && A.lanesPerPixel >= 2;
     const int mode = !full ? (together ? 0 : 5) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
     A.runIf = nullptr;
     A.defer = Deferred {};
