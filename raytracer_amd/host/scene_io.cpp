@@ -522,6 +522,63 @@ int paeth(int a, int b, int c)
 
 } // namespace
 
+Image decodeJpeg(const std::vector<unsigned char>& bytes, const std::string& file); // jpeg.cpp
+
+namespace {
+
+uint32_t le32(const unsigned char* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24); }
+
+// Uncompressed Windows bitmaps of 8 (palette), 24 and 32 bits per pixel, rows bottom-up or
+// top-down; 32-bit files with channel masks other than B, G, R in the low three bytes and
+// every compressed kind are rejected.
+Image decodeBmp(const std::vector<unsigned char>& d, const std::string& file)
+{
+    if (d.size() < 54)
+        throw RtIoError(file + ": truncated BMP header");
+    const uint32_t offset = le32(&d[10]), headerSize = le32(&d[14]);
+    if (headerSize < 40)
+        throw RtIoError(file + ": BMP core headers are not supported");
+    const int32_t w = int32_t(le32(&d[18])), hRaw = int32_t(le32(&d[22]));
+    const int bpp = d[28] | (d[29] << 8);
+    const uint32_t compression = le32(&d[30]);
+    const bool masks = compression == 3 && bpp == 32 && d.size() >= 66 && le32(&d[54]) == 0x00ff0000u && le32(&d[58]) == 0x0000ff00u && le32(&d[62]) == 0x000000ffu;
+    if (compression != 0 && !masks)
+        throw RtIoError(file + ": compressed BMPs are not supported");
+    if (bpp != 8 && bpp != 24 && bpp != 32)
+        throw RtIoError(file + ": only BMPs of 8, 24 or 32 bits per pixel are supported");
+    const bool topDown = hRaw < 0;
+    const int64_t h = topDown ? -int64_t(hRaw) : hRaw;
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536)
+        throw RtIoError(file + ": bad BMP size");
+    const size_t stride = (size_t(w) * size_t(bpp) / 8 + 3) & ~size_t(3);
+    if (size_t(offset) + stride * size_t(h) > d.size())
+        throw RtIoError(file + ": truncated BMP pixel data");
+    const unsigned char* palette = &d[14 + headerSize];
+    uint32_t colours = le32(&d[46]);
+    if (bpp == 8) {
+        if (colours == 0)
+            colours = 256;
+        if (14 + size_t(headerSize) + 4 * size_t(colours) > d.size() || colours > 256)
+            throw RtIoError(file + ": truncated BMP palette");
+    }
+    Image img;
+    img.width = w;
+    img.height = int(h);
+    img.pixels.reserve(size_t(w) * size_t(h));
+    for (int64_t y = 0; y < h; y++) {
+        const unsigned char* row = &d[offset + stride * size_t(topDown ? y : h - 1 - y)];
+        for (int x = 0; x < w; x++) {
+            const unsigned char* px = bpp == 8 ? (row[x] < colours ? palette + 4 * size_t(row[x]) : nullptr) : row + size_t(x) * size_t(bpp / 8);
+            if (!px)
+                throw RtIoError(file + ": BMP palette index out of range");
+            img.pixels.emplace_back(px[2] / 255.0f, px[1] / 255.0f, px[0] / 255.0f);
+        }
+    }
+    return img;
+}
+
+} // namespace
+
 Image loadImage(const std::string& file)
 {
     std::ifstream in(file, std::ios::binary);
@@ -529,8 +586,12 @@ Image loadImage(const std::string& file)
         throw RtIoError("texture file " + file + " does not exist");
     std::vector<unsigned char> data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
     static const unsigned char magic[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    if (data.size() >= 3 && data[0] == 0xff && data[1] == 0xd8 && data[2] == 0xff)
+        return decodeJpeg(data, file);
+    if (data.size() >= 2 && data[0] == 'B' && data[1] == 'M')
+        return decodeBmp(data, file);
     if (data.size() < 8 || std::memcmp(data.data(), magic, 8) != 0)
-        throw RtIoError(file + ": only PNG textures are supported");
+        throw RtIoError(file + ": only PNG, JPEG and BMP textures are supported");
     uint32_t width = 0, height = 0;
     int depth = 0, colorType = 0, interlace = 0;
     std::vector<unsigned char> compressed, palette;

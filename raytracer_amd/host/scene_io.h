@@ -1,4 +1,4 @@
-// Scene ingest on the host: Wavefront OBJ / MTL meshes and PNG textures into the
+// Scene ingest on the host: Wavefront OBJ / MTL meshes and PNG / JPEG / BMP textures into the
 // rt::Mesh / rt::Image types that BvhInterface flattens and uploads.
 //
 //   loadMesh   framework/src/mesh.cpp:52-176 (loadMesh + centerAndScaleToUnitMesh),
@@ -32,6 +32,9 @@ std::vector<Mesh> loadMesh(const std::string& file, bool centerAndNormalize = fa
 
 // Non-interlaced PNG: grey / palette at 1, 2, 4, 8 bits, grey+alpha / RGB / RGBA at 8,
 // anything at 16 bits (high byte kept), as stb_image's 8-bit path delivers them.
+// JPEG: Huffman-coded baseline and progressive frames of 1, 3 or 4 components with
+// stb_image's inverse DCT, chroma upsampling and colour conversion (jpeg.cpp).
+// BMP: uncompressed, 8 (palette), 24 or 32 bits per pixel.
 Image loadImage(const std::string& file);
 
 } // namespace rt

@@ -426,9 +426,77 @@ def make_config():
     np.savez_compressed(os.path.join(OUT, "config.npz"), **out)
 
 
+def _ref_image(path):
+    R = RefEngine.__new__(RefEngine)
+    fn = R.fn("image_load")
+    w, h = C.c_int(), C.c_int()
+    fn(path.encode(), C.byref(w), C.byref(h), None)
+    out = np.zeros((h.value, w.value, 3), np.float32)
+    fn(path.encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def jpeg_cases():
+    """(name, keyword arguments of jpeg_writer.write_jpeg): every sampling layout, scan layout and
+    colour convention the reference's loader (stb_image) tells apart."""
+    rng = np.random.default_rng(5)
+
+    def smooth(h, w, n):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([128 + 100 * np.sin(x / 5 + c) * np.cos(y / 7 - c) + rng.normal(0, 12, (h, w)) for c in range(n)], 2)
+        return np.clip(img, 0, 255).astype(np.uint8)
+
+    return [
+        ("grey", dict(samples=smooth(17, 33, 1))),
+        ("c444", dict(samples=smooth(16, 24, 3))),
+        ("c422", dict(samples=smooth(19, 35, 3), sampling=[(2, 1), (1, 1), (1, 1)])),
+        ("c440", dict(samples=smooth(21, 18, 3), sampling=[(1, 2), (1, 1), (1, 1)])),
+        ("c420_restart", dict(samples=smooth(37, 41, 3), sampling=[(2, 2), (1, 1), (1, 1)], restart=2)),
+        ("c411", dict(samples=smooth(15, 50, 3), sampling=[(4, 1), (1, 1), (1, 1)])),
+        ("c410", dict(samples=smooth(40, 40, 3), sampling=[(4, 2), (1, 1), (1, 1)])),
+        ("one_pixel", dict(samples=smooth(1, 1, 3), sampling=[(2, 2), (1, 1), (1, 1)])),
+        ("two_wide", dict(samples=smooth(9, 2, 3), sampling=[(2, 1), (1, 1), (1, 1)])),
+        ("scan_per_component", dict(samples=smooth(20, 28, 3), sampling=[(2, 2), (1, 1), (1, 1)], interleaved=False, restart=3)),
+        ("rgb_by_ids", dict(samples=smooth(12, 12, 3), ids=[ord("R"), ord("G"), ord("B")])),
+        ("adobe_rgb", dict(samples=smooth(12, 12, 3), jfif=False, adobe=0)),
+        ("adobe_rgb_but_jfif", dict(samples=smooth(12, 12, 3), jfif=True, adobe=0)),
+        ("cmyk", dict(samples=smooth(13, 11, 4), jfif=False, adobe=0)),
+        ("ycck", dict(samples=smooth(13, 11, 4), jfif=False, adobe=2, sampling=[(2, 2), (1, 1), (1, 1), (2, 2)])),
+        ("four_components_no_adobe", dict(samples=smooth(10, 10, 4), jfif=False)),
+        ("progressive_420", dict(samples=smooth(33, 47, 3), sampling=[(2, 2), (1, 1), (1, 1)], progressive=True)),
+        ("progressive_444_restart", dict(samples=smooth(24, 24, 3), progressive=True, restart=2, filler=True)),
+        ("progressive_grey", dict(samples=smooth(30, 19, 1), progressive=True)),
+        ("progressive_scan_per_component", dict(samples=smooth(18, 27, 3), sampling=[(2, 1), (1, 1), (1, 1)], progressive=True, interleaved=False)),
+        ("noise", dict(samples=rng.integers(0, 256, (24, 24, 3), dtype=np.uint8), quality_tables=[np.ones(64, int)] * 2)),
+        ("progressive_noise", dict(samples=rng.integers(0, 256, (16, 16, 3), dtype=np.uint8), quality_tables=[np.ones(64, int) * 2] * 2,
+                                   progressive=True, sampling=[(2, 2), (1, 1), (1, 1)])),
+    ]
+
+
+def make_jpeg():
+    """JPEG files written by tests/golden/jpeg_writer.py (seeded) and what the reference's Image
+    class (framework/src/image.cpp:13-36, stb_image) reads from them; plus a digest of what it
+    reads from the one JPEG the reference ships (data/environment_map_cylindrical.jpg)."""
+    import hashlib
+    from jpeg_writer import write_jpeg
+    d = os.path.join(OUT, "jpeg")
+    os.makedirs(d, exist_ok=True)
+    imgs = {}
+    for name, kw in jpeg_cases():
+        path = os.path.join(d, name + ".jpg")
+        write_jpeg(path, seed=len(name), **kw)
+        imgs[name] = _ref_image(path)
+        print("jpeg", name, os.path.getsize(path), imgs[name].shape)
+    own = _ref_image("/root/reference/data/environment_map_cylindrical.jpg")
+    imgs["reference_environment_map_shape"] = np.array(own.shape)
+    imgs["reference_environment_map_sha256"] = np.frombuffer(hashlib.sha256(own.tobytes()).digest(), np.uint8)
+    imgs["reference_environment_map_rows"] = own[::37].copy()
+    np.savez_compressed(os.path.join(d, "images.npz"), **imgs)
+
+
 if __name__ == "__main__":
     if not have_ref():
         sys.exit("oracle/_ref/libref.so is missing: run `make -C oracle ref` where /root/reference exists")
-    what = sys.argv[1:] or ["scenes", "bvh", "rays", "images", "shade", "kat", "obj", "config"]
+    what = sys.argv[1:] or ["scenes", "bvh", "rays", "images", "shade", "kat", "obj", "config", "jpeg"]
     for w in what:
         globals()["make_" + w]()

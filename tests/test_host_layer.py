@@ -167,6 +167,59 @@ def test_png_reader_matches_the_reference_image_class():
         engine.load_obj(os.path.join(d, "no_such_file.obj"))
 
 
+def test_jpeg_reader_matches_the_reference_image_class(tmp_path):
+    """Baseline and progressive files of every sampling / scan / colour layout, against what the
+    reference's loader (stb_image through framework/src/image.cpp:13-36) read from the same files."""
+    import hashlib
+    d = os.path.join(cases.GOLDEN, "jpeg")
+    with np.load(os.path.join(d, "images.npz")) as z:
+        names = [n for n in z.files if not n.startswith("reference_")]
+        assert len(names) >= 22
+        for name in names:
+            got = engine.load_image(os.path.join(d, name + ".jpg"))
+            assert got.shape == z[name].shape and np.array_equal(bits(got), bits(z[name])), name
+        own = "/root/reference/data/environment_map_cylindrical.jpg"     # 2000 x 666, 4:2:0; only in the build container
+        if os.path.exists(own):
+            got = engine.load_image(own)
+            assert tuple(z["reference_environment_map_shape"]) == got.shape
+            assert np.array_equal(bits(got[::37]), bits(z["reference_environment_map_rows"]))
+            assert hashlib.sha256(got.tobytes()).digest() == z["reference_environment_map_sha256"].tobytes()
+    # what is not read is refused, never guessed at
+    raw = open(os.path.join(d, "c420_restart.jpg"), "rb").read()
+    sof = raw.index(b"\xff\xc0")
+    for name, data in (("cut_short", raw[:len(raw) // 2]), ("arithmetic", raw[:sof] + b"\xff\xc9" + raw[sof + 2:]),
+                       ("twelve_bit", raw[:sof + 4] + b"\x0c" + raw[sof + 5:]), ("no_frame", raw[:sof] + b"\xff\xd9")):
+        (tmp_path / (name + ".jpg")).write_bytes(data)
+        with pytest.raises(RuntimeError):
+            engine.load_image(str(tmp_path / (name + ".jpg")))
+
+
+def test_bmp_reader(tmp_path):
+    """24-bit bottom-up, 32-bit top-down and 8-bit palette bitmaps (what the reference reads through stb_image)."""
+    import struct
+    rng = np.random.default_rng(3)
+    px = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+
+    def header(bpp, h, extra=0, colours=0):
+        stride = (7 * bpp // 8 + 3) & ~3
+        return b"BM" + struct.pack("<IHHI", 54 + extra + stride * 5, 0, 0, 54 + extra) + struct.pack("<IiiHHIIiiII", 40, 7, h, 1, bpp, 0, stride * 5, 2835, 2835, colours, 0)
+
+    rows24 = b"".join(px[y, :, ::-1].tobytes() + b"\0" * 3 for y in range(4, -1, -1))
+    (tmp_path / "a.bmp").write_bytes(header(24, 5) + rows24)
+    rows32 = b"".join(np.concatenate([px[y, :, ::-1], np.full((7, 1), 9, np.uint8)], 1).tobytes() for y in range(5))
+    (tmp_path / "b.bmp").write_bytes(header(32, -5) + rows32)
+    palette = rng.integers(0, 256, (16, 4), dtype=np.uint8)
+    index = rng.integers(0, 16, (5, 7), dtype=np.uint8)
+    (tmp_path / "c.bmp").write_bytes(header(8, 5, extra=64, colours=16) + palette.tobytes() + b"".join(index[y].tobytes() + b"\0" for y in range(4, -1, -1)))
+    want = px.astype(np.float32) / np.float32(255)
+    assert np.array_equal(engine.load_image(str(tmp_path / "a.bmp")), want)
+    assert np.array_equal(engine.load_image(str(tmp_path / "b.bmp")), want)
+    assert np.array_equal(engine.load_image(str(tmp_path / "c.bmp")), palette[index][:, :, 2::-1].astype(np.float32) / np.float32(255))
+    (tmp_path / "d.bmp").write_bytes((header(24, 5) + rows24)[:80])
+    with pytest.raises(RuntimeError):
+        engine.load_image(str(tmp_path / "d.bmp"))
+
+
 def test_empty_scene_and_single_triangle():
     s = SceneData()
     flat = engine.flatten(s, abi.features(accel_structure=1))
