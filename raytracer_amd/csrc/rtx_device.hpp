@@ -594,8 +594,15 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
         return;
     for (;;) {
         if (cur >= 0) {
+#ifdef RTX_PROBE
+            tc.waveOuter += (threadIdx.x & 63u) == 0u;
+            tc.outer += act ? 1u : 0u;
+#endif
             const UniformF4* p = nodes + size_t(uint32_t(cur)) * kWaveNodeQuads;
             const NF4 XL = p[0], XH = p[1], YL = p[2], YH = p[3], ZL = p[4], ZH = p[5], R = p[6];
+            // (the children's references come with the boxes, not in a second round trip to memory
+            // once a child turns out to be entered: the empty statement keeps the load up here)
+            asm volatile("" ::"s"(R.x), "s"(R.y), "s"(R.z), "s"(R.w));
             const float limit = act ? t : -inf; // (a lane that sits this subtree out enters nothing)
             const float k0 = childKey<MODE, ANYSIGN>(XL.x, YL.x, ZL.x, XH.x, YH.x, ZH.x, om, im, limit);
             const float k1 = childKey<MODE, ANYSIGN>(XL.y, YL.y, ZL.y, XH.y, YH.y, ZH.y, om, im, limit);
@@ -629,11 +636,12 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
             }
         } else {
             // a leaf: its triangles one after the other, for the lanes that entered it
-            uint32_t k = uint32_t(~cur);
-            for (;;) {
-                const UniformF4* q = tris + size_t(k) * kWaveTriQuads;
-                const NF4 P = q[0], A = q[1];
+            auto test = [&](const NF4& P, const NF4& A, const NF4& B, const NF4& E0, const NF4& E1, const NF4& C, uint32_t k) -> bool {
                 const bool last = __float_as_int(A.w) < 0; // (top bit of the id word)
+#ifdef RTX_PROBE
+                tc.waveInner += (threadIdx.x & 63u) == 0u;
+                tc.inner += act ? 1u : 0u;
+#endif
                 if (COUNT)
                     tc.triTests += act ? 1u : 0u;
                 // the plane part of triangleTest
@@ -642,7 +650,6 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                 const float th = (P.w - no) / dn;
                 bool ok = act && !(dn == 0.f) && !(th <= 0.f) && (th < t);
                 if (anyLane(ok)) {
-                    const NF4 B = q[2], E0 = q[3], E1 = q[4], C = q[5];
                     const V3 n = mk(P.x, P.y, P.z);
                     const V3 pt = o + th * d;
                     const V3 e0 = pt - mk(A.x, A.y, A.z), e1 = pt - mk(B.x, B.y, B.z);
@@ -659,17 +666,31 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                         }
                     }
                 }
-                if (last || !anyLane(act))
+                return last || !anyLane(act);
+            };
+            // Two whole records per round trip to memory (a leaf's triangles lie one behind the
+            // other): the walk of a wave that has the SIMD to itself -- the long units a frame ends
+            // on -- is a chain of such round trips, and fetching the edge vectors only after the
+            // plane test, triangle by triangle, made it four times as long.  The record behind a
+            // leaf's last one is another leaf's, or the array's padding, and is not looked at.
+            uint32_t k = uint32_t(~cur);
+            for (;;) {
+                const UniformF4* q = tris + size_t(k) * kWaveTriQuads;
+                const NF4 P0 = q[0], A0 = q[1], B0 = q[2], E00 = q[3], E10 = q[4], C0 = q[5];
+                const NF4 P1 = q[6], A1 = q[7], B1 = q[8], E01 = q[9], E11 = q[10], C1 = q[11];
+                asm volatile("" ::"s"(B0.x), "s"(E00.x), "s"(E10.x), "s"(C0.x), "s"(P1.x), "s"(A1.x), "s"(B1.x), "s"(E01.x), "s"(E11.x), "s"(C1.x));
+                if (test(P0, A0, B0, E00, E10, C0, k) || test(P1, A1, B1, E01, E11, C1, k + 1))
                     break;
-                k++;
+                k += 2;
             }
         }
         bool have = false;
         while (sp > 0) {
             const float key = st.waveKey(--sp);
+            const int32_t ref = st.waveRef(sp); // (read with the key, not after the vote)
             act = alive && !(t < key);
             if (anyLane(act)) {
-                cur = st.waveRef(sp);
+                cur = ref;
                 have = true;
                 break;
             }

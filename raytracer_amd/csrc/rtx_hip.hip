@@ -3665,7 +3665,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
         waveStackNeed = need[0];
     }
     const size_t nWide = wide.size();
-    std::vector<float> waveNodes(nWide * 8 * 32, 0.f), waveTris(size_t(d->n_tris) * 24, 0.f);
+    std::vector<float> waveNodes(nWide * 8 * 32, 0.f), waveTris((size_t(d->n_tris) + 1) * 24, 0.f); // (one record of padding: the walk fetches triangles in pairs)
     for (uint32_t oct = 0; oct < 8; oct++)
         for (size_t i = 0; i < nWide; i++) {
             const Wide& w = wide[i];
@@ -3940,7 +3940,7 @@ rtx_scene* rtx_scene_build_device(const rtx_scene_desc* d)
     };
     O.records = static_cast<float4*>(keep((size_t(nNodes) + n) * 64));
     O.waveNodes = static_cast<float4*>(keep(size_t(nWide) * 8 * 128));
-    O.waveTris = static_cast<float4*>(keep(size_t(n) * 96));
+    O.waveTris = static_cast<float4*>(keep((size_t(n) + 1) * 96)); // (one record of padding: the walk fetches triangles in pairs)
     O.attrs = static_cast<rtx_tri_attr*>(keep(size_t(n) * sizeof(rtx_tri_attr)));
     O.idOrder = static_cast<int32_t*>(keep(size_t(n) * 4));
     float rootBox[6] = {}, cut[1 + kMaxCutBoxes * 6] = {};

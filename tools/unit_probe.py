@@ -1,11 +1,11 @@
 # per-unit loop trips, start and duration of one rank's share of the headline
-# frame (needs a diagnostic library build: hipcc $(HIPFLAGS) -DRTX_PROBE -shared -o exp/probe.so raytracer_amd/csrc/rtx_hip.hip;
+# frame (needs a diagnostic library build: hipcc $(HIPFLAGS) -DRTX_PROBE -shared -o tools/_probe.so raytracer_amd/csrc/rtx_hip.hip;
 # the script puts it in place of librtx_hip.so in the tree it runs in, so run it on the GPU box's scratch copy only)
 import ctypes as C, os, sys, shutil
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-shutil.copy(os.path.join(ROOT, "exp", "probe.so"), os.path.join(ROOT, "raytracer_amd", "librtx_hip.so"))
+shutil.copy(os.path.join(ROOT, "tools", "_probe.so"), os.path.join(ROOT, "raytracer_amd", "librtx_hip.so"))
 import torch
 from raytracer_amd import abi, engine
 from raytracer_amd.scene import dragon_scene, make_camera, make_params
