@@ -88,16 +88,24 @@ def workload(name, args):
     headline      BASELINE configs[1] (the metric's own configuration; the default)
     area_glossy   BASELINE configs[2]: the same mesh with a glossy material under one parallelogram
                   light, 64 shadow samples, glossy reflections (fans of 5) to depth 4, 1 spp
+    winding       the headline configuration on the harder stand-in mesh (a coiled body with thin wings, legs
+                  and spikes: rays cross it several times)
     big_scene     BASELINE configs[4]'s geometry: 122 instances of the mesh baked to 9 994 240
                   triangles, 3840x2160, 16 spp jittered"""
     from raytracer_amd import abi
-    from raytracer_amd.scene import SceneData, dragon_scene, instanced_scene
+    from raytracer_amd.scene import SceneData, dragon_scene, instanced_scene, winding_dragon_scene
     base = dict(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
     if name == "headline":
         scene = SceneData.load(args.obj_npz) if args.obj_npz else dragon_scene()
         return dict(scene=scene, features=abi.features(**base), params=dict(driver=abi.DRIVER_MRAYS, samples=args.spp), ref_mode=0,
                     metric="Mrays/s (primary+secondary), dragon 1080p 16spp",
                     text=f"dragon stand-in ({scene.n_triangles} tris, seeded; dragon.obj is absent from the reference checkout) "
+                         f"{args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light")
+    if name == "winding":
+        scene = winding_dragon_scene()
+        return dict(scene=scene, features=abi.features(**base), params=dict(driver=abi.DRIVER_MRAYS, samples=args.spp), ref_mode=0,
+                    metric="Mrays/s (primary+secondary), dragon 1080p 16spp",
+                    text=f"winding dragon stand-in ({scene.n_triangles} tris, seeded: coiled body, thin wings, legs, spikes) "
                          f"{args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light")
     if name == "area_glossy":
         scene = dragon_scene()
@@ -155,8 +163,10 @@ def main():
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-GPU render of it")
     ap.add_argument("--no-every-block", action="store_true", help="skip the second timing of the frame with no block declared unable to see the scene (roofline.kernel_ms_every_block_traced)")
     ap.add_argument("--force-pipeline", action="store_true", help="rehearsal: run the N > 1 code path (tiles, gather, assembly) in a one-rank group")
-    ap.add_argument("--workload", default="headline", choices=["headline", "area_glossy", "big_scene"],
+    ap.add_argument("--workload", default="headline", choices=["headline", "winding", "area_glossy", "big_scene"],
                     help="headline = BASELINE configs[1], the metric's configuration; area_glossy = configs[2]; big_scene = configs[4]'s geometry")
+    ap.add_argument("--tree", default="auto", choices=["auto", "host", "gpu"],
+                    help="where the BVH is built: host = the reference's tree (default for headline, area_glossy); gpu = rtx_scene_build_device (default for big_scene)")
     args = ap.parse_args()
     if args.workload == "big_scene" and (args.width, args.height) == (1920, 1080):
         args.width, args.height = 3840, 2160
@@ -196,7 +206,11 @@ def main():
     cam_in = make_camera()
 
     t_build = time.perf_counter()
-    gpu = engine.GpuEngine(scene, features, device=local_rank)   # host BVH build + flatten + one upload
+    # the reference's tree, built on the host and uploaded once; the scene of millions of triangles gets
+    # its tree on the GPU (a Morton-order tree, same hits), so that the ranks of a node do not each run a
+    # threaded host build of seconds on the same cores
+    device_build = args.tree == "gpu" or (args.tree == "auto" and args.workload == "big_scene")
+    gpu = engine.GpuEngine(scene, features, device=local_rank, device_build=device_build)
     t_build = time.perf_counter() - t_build
     dscene = gpu.device_scene()
     cam = engine.device_camera(cam_in, args.width, args.height)
@@ -284,7 +298,7 @@ def main():
     # for the record: the same frame on a tree built on the GPU (rtx_scene_build_device; the timed
     # frames above use the host-built tree, which is the reference's)
     device_tree = None
-    if not grouped and not args.no_every_block:
+    if not grouped and not args.no_every_block and not device_build:
         t_dev = time.perf_counter()
         gpu2 = engine.GpuEngine(scene, features, device=local_rank, device_build=True)
         t_dev = time.perf_counter() - t_dev
@@ -313,7 +327,8 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["text"] + f", sweep-split BVH ({gpu.levels()} levels, {gpu.leaves()} leaves)",
+            "config": {"workload": wl["text"] + (f", Morton-order BVH built on the GPU ({gpu.levels()} levels, {gpu.leaves()} leaves)" if device_build
+                                                    else f", sweep-split BVH ({gpu.levels()} levels, {gpu.leaves()} leaves)"),
                        "rays_per_frame": int(rays_frame), "primary": int(counts[0]), "shadow": int(counts[1]), "bounce": int(counts[2]),
                        # one "ray" = one BvhInterface::intersect call of the reference.  The device does not make
                        # the camera rays of 8x8 blocks that cannot see the scene's bounds (the reference tests

@@ -194,6 +194,109 @@ def dragon_scene(seed=1, subdivisions=6):
     return s
 
 
+def _tube(centres, radii, around, wobble=None):
+    """A closed tube: rings of `around` vertices about the polyline `centres` (parallel-transported
+    frames, so the rings do not twist), radius per ring, end caps as fans.  -> (vertices, faces)"""
+    centres = np.asarray(centres, np.float64)
+    n = len(centres)
+    tang = np.gradient(centres, axis=0)
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True)
+    u = np.cross(tang[0], [0.0, 0.0, 1.0])
+    if np.linalg.norm(u) < 1e-6:
+        u = np.cross(tang[0], [0.0, 1.0, 0.0])
+    u /= np.linalg.norm(u)
+    phi = np.linspace(0, 2 * math.pi, around, endpoint=False)
+    verts = []
+    for i in range(n):
+        u = u - tang[i] * (u @ tang[i])
+        u /= np.linalg.norm(u)
+        w = np.cross(tang[i], u)
+        r = radii[i] * (1.0 if wobble is None else wobble[i])
+        verts.append(centres[i] + np.outer(np.cos(phi), u) * r + np.outer(np.sin(phi), w) * r)
+    verts = np.concatenate(verts + [centres[:1], centres[-1:]])
+    i, j = np.meshgrid(np.arange(n - 1), np.arange(around), indexing="ij")
+    a, b = i * around + j, i * around + (j + 1) % around
+    faces = np.concatenate([np.stack([a, b, a + around], 2).reshape(-1, 3), np.stack([b, b + around, a + around], 2).reshape(-1, 3)])
+    k = np.arange(around)
+    head, tail = n * around, n * around + 1
+    caps = np.concatenate([np.stack([np.full(around, head), (k + 1) % around, k], 1),
+                           np.stack([np.full(around, tail), (n - 1) * around + k, (n - 1) * around + (k + 1) % around], 1)])
+    return verts, np.concatenate([faces, caps])
+
+
+def winding_dragon(seed=1, material=(0.8, 0.6, 0.4, 0.0, 0.0, 0.0, 1.0, 1.0), detail=1.0):
+    """A second, harder seeded stand-in for data/dragon.obj (about 87 K triangles at detail 1):
+    a body that winds through space in an S (so rays cross it several times: depth complexity
+    up to six, against two for the lumpy ball of dragon_standin), tapering into a long thin tail
+    and neck, with a scaly surface, two thin curved wing membranes, four thin legs and a row of
+    spikes along the back.  Normalised to the unit ball like loadMesh(..., normalize=true)."""
+    rng = np.random.default_rng(seed)
+    parts = []
+
+    def add(v, f):
+        parts.append((np.asarray(v, np.float64), np.asarray(f, np.int64)))
+
+    rings, around = max(8, int(380 * detail)), max(6, int(96 * detail))
+    s = np.linspace(0.0, 1.0, rings)
+    turn = 2 * math.pi * 1.6 * s + 0.5
+    spine = np.stack([0.62 * np.cos(turn) * (0.55 + 0.45 * s) + 0.10 * np.sin(9 * s), 1.05 * (s - 0.5) + 0.16 * np.sin(2 * math.pi * 2.2 * s),
+                      0.62 * np.sin(turn) * (0.55 + 0.45 * s)], 1)
+    radius = 0.02 + 0.21 * np.sin(math.pi * np.clip(s * 1.12 - 0.04, 0, 1)) ** 1.4
+    radius[s > 0.86] += 0.05 * np.sin(math.pi * (s[s > 0.86] - 0.86) / 0.14)          # the head
+    scales = 1.0 + 0.06 * np.sin(s * rings * 0.9) + 0.03 * rng.normal(size=rings)
+    body_v, body_f = _tube(spine, radius, around, scales)
+    ring_phase = np.tile(np.sin(np.arange(around) * 8 * 2 * math.pi / around), rings)
+    body_v[:rings * around] += 0.012 * ring_phase[:, None] * (body_v[:rings * around] - np.repeat(spine, around, axis=0))
+    add(body_v, body_f)
+    # wings: thin closed shells, curved, attached behind the shoulders
+    gu, gv = max(4, int(44 * detail)), max(3, int(26 * detail))
+    for side in (-1.0, 1.0):
+        a, b = np.meshgrid(np.linspace(0, 1, gu), np.linspace(0, 1, gv), indexing="ij")
+        root = spine[int(rings * 0.62)]
+        span = 0.75 * a
+        px = root[0] - 0.15 + 0.55 * b - 0.25 * a * a
+        py = root[1] + 0.10 + 0.45 * np.sin(a * 2.2) - 0.08 * np.sin(b * 9) * a
+        pz = root[2] + side * (0.12 + span)
+        top = np.stack([px, py + 0.006, pz], 2).reshape(-1, 3)
+        bot = np.stack([px, py - 0.006, pz], 2).reshape(-1, 3)
+        i, j = np.meshgrid(np.arange(gu - 1), np.arange(gv - 1), indexing="ij")
+        q = (i * gv + j).reshape(-1)
+        quad = np.concatenate([np.stack([q, q + gv, q + 1], 1), np.stack([q + 1, q + gv, q + gv + 1], 1)])
+        add(top, quad if side > 0 else quad[:, ::-1])
+        add(bot, quad[:, ::-1] if side > 0 else quad)
+    # legs
+    for at, side in ((0.40, -1.0), (0.40, 1.0), (0.68, -1.0), (0.68, 1.0)):
+        hip = spine[int(rings * at)]
+        tt = np.linspace(0, 1, max(4, int(30 * detail)))
+        leg = np.stack([hip[0] + 0.10 * tt * tt, hip[1] - 0.45 * tt, hip[2] + side * (0.10 + 0.12 * np.sin(tt * 2.5))], 1)
+        add(*_tube(leg, 0.045 * (1.0 - 0.75 * tt), max(5, int(16 * detail))))
+    # spikes along the back
+    for at in np.linspace(0.2, 0.84, max(3, int(24 * detail))):
+        base = spine[int(rings * at)] + np.array([0.0, radius[int(rings * at)] * 0.9, 0.0])
+        tt = np.linspace(0, 1, 6)
+        spike = base + np.outer(tt, [-0.03, 0.13, 0.0])
+        add(*_tube(spike, 0.022 * (1.0 - 0.95 * tt), max(4, int(10 * detail))))
+    offset, vs, fs = 0, [], []
+    for v, f in parts:
+        vs.append(v)
+        fs.append(f + offset)
+        offset += len(v)
+    pos = _normalize_unit(np.concatenate(vs))
+    tris = np.concatenate(fs).astype(np.uint32)
+    nrm = _vertex_normals(pos.astype(np.float64), tris)
+    uv = np.stack([pos[:, 0] * 0.5 + 0.5, pos[:, 2] * 0.5 + 0.5], 1)
+    verts = np.concatenate([pos, nrm, uv.astype(np.float32)], axis=1).astype(np.float32)
+    return MeshData(verts, tris, material)
+
+
+def winding_dragon_scene(seed=1, detail=1.0):
+    """SceneType::Dragon (src/scene.cpp:68-73) with the winding stand-in mesh."""
+    s = SceneData()
+    s.meshes.append(winding_dragon(seed, detail=detail))
+    s.lights.append(abi.point_light((-1, 1, -1), (1, 1, 1)))
+    return s
+
+
 def instanced_scene(copies, seed=1, subdivisions=6, transparent_every=3):
     """BASELINE configs[4] stand-in: `copies` instances of the seeded mesh baked to
     flat triangles on a jittered cubic grid inside the unit cube (122 copies =

@@ -665,6 +665,61 @@ def test_dragon_standin_full_size_properties(gpu_device):
     gpu.close()
 
 
+def test_winding_dragon_standin_against_the_oracle(gpu_device):
+    """The harder stand-in (a body coiled through space, thin wing membranes, legs, spikes: rays
+    cross it several times, many graze it): frames, ray counts and primary hits against the oracle,
+    on the host-built and on the device-built tree, under hard shadows and under an area light with
+    glossy reflections; determinism and count identities at the full 1920x1080x16."""
+    from raytracer_amd.scene import winding_dragon_scene
+    scene = winding_dragon_scene()
+    f = abi.features(**cases.BASE)
+    cam = make_camera()
+    gpu, dev, orc = GpuEngine(scene, f), GpuEngine(scene, f, device_build=True), OracleEngine(scene, f)
+    small = make_params(96, 54, driver=abi.DRIVER_MRAYS, samples=16)
+    want = orc.render(cam, f, small)
+    counts = tuple(int(x) for x in orc.counters[:3])
+    for name, e in (("host tree", gpu), ("device tree", dev)):
+        assert_images_close(e.render(cam, f, small), want, f"winding stand-in 96x54x16, {name}")
+        assert (e.stats.rays_primary, e.stats.rays_shadow, e.stats.rays_bounce) == counts, name
+    rays = primary_rays(cam, 1920, 1080, step=24)
+    wanted = orc.intersect(rays, f)
+    assert 0.03 < (wanted["hit"] != 0).mean() < 0.5
+    assert assert_hits_equal(gpu.intersect(rays, f), wanted, "winding stand-in primary rays") == 0
+    got = dev.intersect(rays, f)
+    hit = wanted["hit"] != 0
+    assert np.array_equal(got["hit"] != 0, hit) and np.array_equal(got["t"][hit].view(np.uint32), wanted["t"][hit].view(np.uint32))
+    # close up and from another side, depth of field (lane-by-lane walk) and one sample per pixel
+    near = make_camera(rotation_degrees=(-30, 140, 0), distance=1.4)
+    for rp in (make_params(80, 45, driver=abi.DRIVER_MRAYS, samples=16), make_params(64, 36, driver=abi.DRIVER_DOF, samples=8, aperture=0.1, focal_length=1.4),
+               make_params(96, 54)):
+        assert_images_close(gpu.render(near, f, rp), orc.render(near, f, rp), f"winding stand-in close-up, driver {rp.driver}")
+    orc.close()
+    # area light + glossy reflections (three-pass frames)
+    soft = abi.features(**dict(cases.BASE, hard_shadow=0, soft_shadow=1, recursive=1, glossy_reflection=1))
+    glossy = winding_dragon_scene(detail=0.5)
+    glossy.lights = [abi.parallelogram_light((-0.2, 0.9, 0.0), (0.4, 0, 0), (0, 0, 0.4), (1, 1, 1), (1, 0.9, 0.8), (0.8, 0.9, 1), (1, 1, 1))]
+    for m in glossy.meshes:
+        m.material[3:6] = 0.5
+        m.material[6] = 50.0
+    g2, o2 = GpuEngine(glossy, soft), OracleEngine(glossy, soft)
+    rp = make_params(64, 36, shadow_samples=16, glossy_rays=5, ray_depth=3)
+    assert_images_close(g2.render(cam, soft, rp), o2.render(cam, soft, rp), "winding stand-in, area light 16 + glossy depth 3")
+    assert (g2.stats.rays_primary, g2.stats.rays_shadow, g2.stats.rays_bounce) == tuple(int(x) for x in o2.counters[:3])
+    g2.close()
+    o2.close()
+    # full size: two runs identical on both trees, which also agree with each other
+    full = make_params(1920, 1080, driver=abi.DRIVER_MRAYS, samples=16)
+    a = gpu.render(cam, f, full)
+    s = gpu.stats
+    assert s.rays_primary == 1920 * 1080 * 16 and s.rays_shadow == s.shaded_hits and 0 < s.rays_shadow < s.rays_primary
+    assert np.array_equal(a, gpu.render(cam, f, full))
+    b = dev.render(cam, f, full)
+    assert (dev.stats.rays_primary, dev.stats.rays_shadow) == (s.rays_primary, s.rays_shadow)
+    assert np.abs(a - b).max() <= RGB_TOL
+    gpu.close()
+    dev.close()
+
+
 def _glossy_dragon():
     """BASELINE configs[2] on the stand-in: one parallelogram light above the mesh, every
     surface glossy (ks = 0.5, shininess 50)."""

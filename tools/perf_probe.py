@@ -21,7 +21,7 @@ def main():
     args = ap.parse_args()
     import torch
     from raytracer_amd import abi, engine
-    from raytracer_amd.scene import dragon_scene, make_camera, make_params
+    from raytracer_amd.scene import dragon_scene, make_camera, make_params, winding_dragon_scene
 
     hip = engine.hip_lib()
     scene = dragon_scene()
@@ -55,6 +55,13 @@ def main():
         ("dof 16 samples", dict(), dict(), dict(driver=abi.DRIVER_DOF, samples=16), None),
         ("motion blur 7 steps", dict(), dict(), dict(driver=abi.DRIVER_MOTION_BLUR, samples=7, prev_camera=engine.device_camera(make_camera(rotation_degrees=(22, 18, 0)), 1920, 1080)), None),
     ]
+    # the harder stand-in mesh (coiled body, thin wings, legs, spikes), host-built and device-built tree
+    variations += [
+        ("winding dragon", dict(), dict(), dict(samples=16), "winding"),
+        ("winding dragon close-up", dict(), dict(distance=1.4, rotation_degrees=(-30, 140, 0)), dict(samples=16), "winding"),
+        ("winding dragon on GPU-built tree", dict(), dict(), dict(samples=16), "winding_dev"),
+        ("winding dragon close-up on GPU-built tree", dict(), dict(distance=1.4, rotation_degrees=(-30, 140, 0)), dict(samples=16), "winding_dev"),
+    ]
     only = [s for s in args.only.split(",") if s]
     dev = torch.device("cuda", 0)
     frame = torch.zeros((1080, 1920, 3), dtype=torch.float32, device=dev)
@@ -65,12 +72,17 @@ def main():
         m.material[3:6] = 0.5
         m.material[6] = 50.0
     gpu_area = None
+    others = {}
     for var in variations:
         name, fchg, cchg, pchg = var[:4]
         if only and name not in only:
             continue
         use = gpu
-        if len(var) > 4 and var[4] is not None:
+        if len(var) > 4 and isinstance(var[4], str):
+            if var[4] not in others:
+                others[var[4]] = engine.GpuEngine(winding_dragon_scene(), abi.features(**base), device_build=var[4].endswith("_dev"))
+            use = others[var[4]]
+        elif len(var) > 4 and var[4] is not None:
             if gpu_area is None:
                 gpu_area = engine.GpuEngine(area_scene, abi.features(**base))
             use = gpu_area
@@ -85,6 +97,8 @@ def main():
             best = min(best, st.kernel_ms)
         print(f"{name:28s} {best:8.3f} ms  rays {st.rays/1e6:8.2f} M  shaded {st.shaded_hits/1e6:6.2f} M  {st.rays/best/1e3:9.1f} Mrays/s", flush=True)
     gpu.close()
+    for e in others.values():
+        e.close()
     if gpu_area is not None:
         gpu_area.close()
 
