@@ -36,7 +36,8 @@ raytracer_amd/render_obj: examples/render_obj.cpp raytracer_amd/librtx_host.so
 raytracer_amd/render_cli: examples/render_cli.cpp raytracer_amd/librtx_host.so
 	$(CXX) $(CXXFLAGS) -o $@ examples/render_cli.cpp -Lraytracer_amd -lrtx_host -lrtx_hip -Wl,-rpath,'$$ORIGIN'
 
-oracle:
+# oracle/_ref/dropin_check links the host library, so that one comes first
+oracle: raytracer_amd/librtx_host.so
 	$(MAKE) -C oracle all
 
 clean:
