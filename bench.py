@@ -165,6 +165,10 @@ def main():
     ap.add_argument("--force-pipeline", action="store_true", help="rehearsal: run the N > 1 code path (tiles, gather, assembly) in a one-rank group")
     ap.add_argument("--workload", default="headline", choices=["headline", "winding", "area_glossy", "big_scene"],
                     help="headline = BASELINE configs[1], the metric's configuration; area_glossy = configs[2]; big_scene = configs[4]'s geometry")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="frames kept in flight on each GPU (1..4): frame i runs in the library's frame slot i %% F on that slot's own stream, "
+                         "so the next frame's waves fill the compute units the previous frame's last, longest work units leave idle; "
+                         "1 = one frame after the other on one stream")
     ap.add_argument("--tree", default="auto", choices=["auto", "host", "gpu"],
                     help="where the BVH is built: host = the reference's tree (default for headline, area_glossy); gpu = rtx_scene_build_device (default for big_scene)")
     args = ap.parse_args()
@@ -215,43 +219,94 @@ def main():
     dscene = gpu.device_scene()
     cam = engine.device_camera(cam_in, args.width, args.height)
     rp = make_params(args.width, args.height, tile_size=args.tile, tile_rank=rank, tile_world=world, **wl["params"])
-    # queue the library's work on a torch stream so events and collectives order with it
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    assert hip.rtx_set_stream(C.c_void_p(stream.cuda_stream)) == 0, hip.rtx_last_error()
+    # queue the library's work on torch streams so events and collectives order with it: one
+    # stream per frame slot (rtx_select_slot), each slot with its own working memory in the library
+    F = max(1, min(4, args.frames_in_flight))
+    streams = engine.concurrent_streams(F, dev)   # (streams that share a hardware queue would take turns)
+    F = len(streams)
+    for k in reversed(range(F)):    # (slot 0 is left selected)
+        assert hip.rtx_select_slot(k) == 0, hip.rtx_last_error()
+        assert streams[k].cuda_stream != 0
+        assert hip.rtx_set_stream(C.c_void_p(streams[k].cuda_stream)) == 0, hip.rtx_last_error()
+    torch.cuda.set_stream(streams[0])
+    stream = streams[0]
+
+    import contextlib
+
+    @contextlib.contextmanager
+    def in_slot(k):
+        """The library's frame slot k and its stream current for the calls inside."""
+        assert hip.rtx_select_slot(k) == 0, hip.rtx_last_error()
+        try:
+            with torch.cuda.stream(streams[k]):
+                yield
+        finally:
+            hip.rtx_select_slot(0)
 
     pixels = args.width * args.height
-    frame = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
+    frames = [torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev) for _ in range(F)]
+    frame = frames[0]
     def check(rc):
         if rc != 0:
             raise RuntimeError(hip.rtx_last_error().decode())
 
     pipe = None
+    last = {"slot": 0, "n": 0}
     if grouped:
         per = hip.rtx_tiles_per_rank(C.byref(rp))
+        def enter(k):
+            last["slot"] = k
+            return in_slot(k)
         pipe = FramePipeline(
             lambda: torch.zeros((per, args.tile, args.tile, 3), dtype=torch.float32, device=dev),
             lambda tiles: check(hip.rtx_render_tiles_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(tiles.data_ptr()), None)),
-            lambda stack: check(hip.rtx_detile_device(C.c_void_p(stack.data_ptr()), C.byref(rp), C.c_void_p(frame.data_ptr()))))
+            lambda stack: check(hip.rtx_detile_device(C.c_void_p(stack.data_ptr()), C.byref(rp), C.c_void_p(frames[last["slot"]].data_ptr()))),
+            slots=F, enter=enter)
 
-    def step(stats=None):
+    def step(stats=None, serial=False):
         if pipe is not None:
             if stats is not None:   # the counted frame: this rank's tiles alone, waited for
                 check(hip.rtx_render_tiles_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(pipe.tiles[0].data_ptr()), C.byref(stats)))
             else:
                 pipe.submit()
-        else:
+        elif stats is not None or serial or F == 1:
             check(hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(frame.data_ptr()), C.byref(stats) if stats is not None else None))
+        else:
+            k = last["n"] % F
+            last["n"] += 1
+            with in_slot(k):
+                check(hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(rp), C.c_void_p(frames[k].data_ptr()), None))
+
+    def join_slots():
+        """Stream 0 waits for everything queued in the other slots."""
+        for k in range(1, F):
+            e = torch.cuda.Event()
+            e.record(streams[k])
+            streams[0].wait_event(e)
 
     # one counted frame: rays per frame (deterministic) and this rank's kernel time
     st = abi.Stats()
     step(st)
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, F)):   # (every slot's first frame measures its blocks for the order)
         step()
     if pipe is not None:
         pipe.drain()
+    torch.cuda.synchronize()
+    # the kernel's own duration, for the roofline: frames one after the other in slot 0, HIP
+    # events on the launch stream (frames in flight together share the chip, so their
+    # individual durations say nothing about the kernel)
+    serial_ms = None
+    if pipe is None:
+        for _ in range(2):
+            step(serial=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            step(serial=True)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        serial_ms = e0.elapsed_time(e1) / args.steps
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the small reductions live
     counts = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce, st.shaded_hits, st.rays_traced], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -269,12 +324,14 @@ def main():
         step()
     if pipe is not None:
         pipe.drain()          # the last frame's gather and assembly belong to the timed region
+    join_slots()
     ev1.record(stream)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps     # HIP events on the launch stream, per frame
+    device_ms = ev0.elapsed_time(ev1) / args.steps     # HIP events around the timed region, per frame (frames in flight overlap)
+    kernel_ms = serial_ms if serial_ms is not None else device_ms
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -318,8 +375,10 @@ def main():
         one = make_params(args.width, args.height, tile_size=args.tile, **wl["params"])
         rc = hip.rtx_render_device(dscene, C.byref(cam), C.byref(features), C.byref(one), C.c_void_p(ref.data_ptr()), None)
         torch.cuda.synchronize()
-        assert rc == 0 and torch.equal(ref, frame), "assembled multi-rank frame differs from the single-GPU frame"
-        print("check ok: assembled frame equals the single-GPU frame", file=sys.stderr)
+        assert rc == 0
+        for k in range(min(F, args.steps + max(args.warmup, F))):
+            assert torch.equal(ref, frames[k]), f"assembled multi-rank frame of slot {k} differs from the single-GPU frame"
+        print(f"check ok: the assembled frame of each of {F} slot(s) equals the single-GPU frame", file=sys.stderr)
     if rank == 0:
         value = rays_frame * args.steps / elapsed / 1e6
         out = {
@@ -335,6 +394,9 @@ def main():
                        # and misses them): rays_traced are the rays that did walk the scene on the device
                        "rays_traced": int(counts[4]), "value_on_rays_traced": round(float(counts[4]) * args.steps / elapsed / 1e6, 2),
                        "partition": "whole frame" if not grouped else f"interleaved {args.tile}x{args.tile} tiles + RCCL gather to rank 0",
+                       # frame i is queued in frame slot i % F (own stream and working memory): the frames of
+                       # different slots share the chip, each frame is rendered (and assembled) in full
+                       "frames_in_flight": F, "device_ms_per_frame": round(device_ms, 4),
                        "bvh_build_upload_s": round(t_build, 3)},
         }
         if device_tree is not None:
@@ -359,6 +421,9 @@ def main():
                 out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                    "kernel": "renderKernel" if args.workload != "area_glossy" else "renderKernel (walk) + lightKernel + resolveKernel",
+                                   # one frame after the other on one stream (HIP events over args.steps frames), the figure
+                                   # the kernel trace's average duration agrees with; the timed region above keeps
+                                   # frames_in_flight frames on the chip at once
                                    "kernel_ms": round(kernel_ms, 4),
                                    "algorithmic_bytes_per_launch": int(alg), "box_tests_per_ray": round(n_aabb, 3),
                                    "tri_tests_per_ray": round(n_tri, 3)}

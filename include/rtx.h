@@ -321,16 +321,36 @@ int rtx_shade_device(const rtx_scene* scene, const rtx_ray* d_rays, size_t n, co
 /* Number of tiles each rank's compact buffer holds (the maximum over ranks). */
 int rtx_tiles_per_rank(const rtx_render_params* params);
 
-/* Queue this GPU's work on the caller's HIP stream (a hipStream_t, e.g.
+/* Queue the work of this thread's frame slot on the caller's HIP stream (a hipStream_t, e.g.
  * the framework stream the device buffers are produced and consumed on) instead
  * of the library's own; NULL switches back.  With a stats pointer of NULL the
  * *_device entry points only enqueue and return, so frames can be pipelined
- * with the caller's other work on that stream.  The setting is per GPU, not per
- * thread: it applies to every thread that has called rtx_init for the same device.  Work still
+ * with the caller's other work on that stream.  The setting belongs to the frame slot
+ * (rtx_select_slot; slot 0 unless another was selected), not to the thread: it applies to every
+ * thread that works in the same slot of the same GPU.  Work still
  * queued on the previous stream is ordered before whatever is queued on the new one (an event
- * on the old stream that the new one waits for), because all calls share the GPU's work
+ * on the old stream that the new one waits for), because all calls in a slot share its work
  * counters and scheduling buffers. */
 int rtx_set_stream(void* hip_stream);
+
+/* Frames in flight.  A GPU has RTX_FRAME_SLOTS frame slots; each holds its own stream, work
+ * counters, statistics, scheduling buffers and deferred-frame pools, so calls made in different
+ * slots share nothing but the (read-only) scene and may run on the GPU at the same time: the
+ * next frame's waves fill the compute units that the last, longest work units of the previous
+ * frame leave idle.  The counterpart in the reference is its command line's one thread per
+ * camera (src/main.cpp:560-585).  rtx_select_slot makes `slot` the one this THREAD's following
+ * calls work in (created on first use; rtx_init selects slot 0).  Calls within one slot stay
+ * serialised and ordered on its stream; ordering between slots is the caller's (events on the
+ * slots' streams, or rtx_synchronize in each).  rtx_render_device_static works in slot 0 only. */
+#define RTX_FRAME_SLOTS 4
+int rtx_select_slot(int slot);
+/* Whether kernels queued on two of the caller's HIP streams run at the same time: 1 = yes, 0 =
+ * they take turns, < 0 = error.  The HIP runtime spreads a process's streams over a few hardware
+ * queues, and streams that share a queue serialise, so frames in different slots only share the
+ * GPU when the slots' streams pass this test (the library's own streams are chosen with it; a
+ * caller that hands its streams to rtx_set_stream picks them with it).  Measured with two
+ * 300-microsecond single-wave kernels; waits for both streams.  No counterpart in the reference. */
+int rtx_streams_overlap(void* hip_stream_a, void* hip_stream_b);
 
 /* Page-locked host memory for buffers that travel to or from the GPU (a framebuffer handed to
  * rtx_render, ray and hit arrays handed to rtx_trace): copies run at the bus's full rate
@@ -340,7 +360,7 @@ int rtx_set_stream(void* hip_stream);
 void* rtx_host_alloc(size_t bytes);
 void  rtx_host_free(void* buffer);
 
-/* Block until all work queued by this thread's calls has finished. */
+/* Block until all work queued in this thread's frame slot has finished. */
 int rtx_synchronize(void);
 
 /* Text of the most recent failure on the calling thread ("" if none). */

@@ -2272,6 +2272,7 @@ static __device__ __align__(256) unsigned char scratch[kFixedBytes];
 
 struct DeviceCtx {
     int device = -1;
+    int slot = 0;                      // which of the GPU's frame slots this is (rtx_select_slot)
     hipStream_t stream = nullptr;      // stream work is queued on (own or caller's)
     hipStream_t ownStream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2321,7 +2322,8 @@ uint64_t hostPowMod(uint64_t base, uint64_t e)
 }
 thread_local DeviceCtx* g_ctx = nullptr;
 std::mutex g_ctxMutex;
-DeviceCtx g_ctxs[64];
+constexpr int kSlots = RTX_FRAME_SLOTS; // frame slots per GPU (rtx_select_slot)
+DeviceCtx g_ctxs[64][kSlots];
 
 } // namespace
 
@@ -3350,9 +3352,153 @@ int uploadShading(rtx_scene* s, const rtx_scene_desc* d)
     return rc;
 }
 
+// Keeps one wave busy for `ticks` of the 100 MHz wall clock (streamsOverlap).
+__global__ void __launch_bounds__(64) spinKernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(8);
+}
+
+// Whether kernels queued on streams `a` and `b` run at the same time.  The runtime spreads a
+// process's streams over a few hardware queues, and two streams that land on the same queue
+// take turns however independent their work is.  Measured: one wave spins for 300 us on each
+// stream; together they take 300 us on different queues and 600 us on one.  1 = they overlap,
+// 0 = they take turns, < 0 = error.  The device is current.
+int streamsOverlap(hipStream_t a, hipStream_t b)
+{
+    if (a == b)
+        return 0;
+    constexpr unsigned long long kSpinTicks = 30000; // 300 us
+    hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess)
+        e = hipEventCreate(&e1);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&eb, hipEventDisableTiming);
+    float ms = 0.f;
+    for (int pass = 0; pass < 2 && e == hipSuccess; pass++) { // (the first pass loads the kernel and wakes the queues)
+        const unsigned long long ticks = pass ? kSpinTicks : 1ull;
+        e = hipEventRecord(e0, a);
+        if (e != hipSuccess)
+            break;
+        hipLaunchKernelGGL(spinKernel, dim3(1), dim3(64), 0, a, ticks);
+        hipLaunchKernelGGL(spinKernel, dim3(1), dim3(64), 0, b, ticks);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipEventRecord(eb, b);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(a, eb, 0);
+        if (e == hipSuccess)
+            e = hipEventRecord(e1, a);
+        if (e == hipSuccess)
+            e = hipEventSynchronize(e1);
+        if (e == hipSuccess)
+            e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    for (hipEvent_t ev : { e0, e1, eb })
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (e != hipSuccess) {
+        setErr("stream overlap probe failed: %s", hipGetErrorString(e));
+        return RTX_ERR_DEVICE;
+    }
+    return ms < 1.6f * float(kSpinTicks) * 1e-5f ? 1 : 0;
+}
+
+// Makes a context (one frame slot of one GPU) ready: its stream, events and working memory.
+// Everything is made in locals and committed at the end, so that a failure halfway leaves
+// nothing behind and a later call starts from scratch.  The caller holds g_ctxMutex and has
+// made `device` current.
+int initCtx(DeviceCtx* c, int device, int slot)
+{
+    if (c->device >= 0)
+        return RTX_OK;
+    hipStream_t stream = nullptr;
+    hipEvent_t events[3] = {};
+    void* mem[6] = {};
+    const size_t bytes[6] = { kTicketBytes + kStatBytes, // one allocation: cleared together
+        (2 * size_t(kJumpMaxDim) + kJumpMaxSamples) * sizeof(uint32_t), (size_t(kMaxOrderedBlocks) + 64) * sizeof(uint32_t),
+        size_t(kMaxOrderedBlocks) * sizeof(uint32_t), size_t(kMaxOrderedBlocks) + 4, size_t(kCostClasses) * (kMaxOrderedBlocks / 64) * sizeof(uint32_t) + 256 };
+    hipDeviceProp_t prop;
+    unsigned char* fixedBase = nullptr;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    // a further slot is there to run beside the others: its stream must not share a hardware
+    // queue with theirs (a handful of tries: the runtime deals its queues out in turn)
+    hipStream_t rejected[8] = {};
+    for (int tries = 0; e == hipSuccess && slot > 0 && tries < 8; tries++) {
+        bool beside = true;
+        for (int k = 0; k < kSlots && beside; k++) {
+            const DeviceCtx* other = &g_ctxs[device][k];
+            if (other != c && other->device >= 0 && streamsOverlap(other->ownStream, stream) == 0)
+                beside = false;
+        }
+        if (beside)
+            break;
+        rejected[tries] = stream;
+        stream = nullptr;
+        e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    }
+    for (hipStream_t r : rejected)
+        if (r)
+            (void)hipStreamDestroy(r);
+    for (int i = 0; i < 3 && e == hipSuccess; i++)
+        e = hipEventCreate(&events[i]);
+    for (int i = 0; i < 6 && e == hipSuccess; i++)
+        e = hipMalloc(&mem[i], bytes[i]);
+    // this GPU's copy of the file-scope array (each device holds its own, at its own address);
+    // it belongs to slot 0
+    if (e == hipSuccess && slot == 0)
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&fixedBase), HIP_SYMBOL(scratch));
+    if (e != hipSuccess) {
+        setErr("rtx_init(%d) failed: %s", device, hipGetErrorString(e));
+        for (void* m : mem)
+            if (m)
+                (void)hipFree(m);
+        for (hipEvent_t ev : events)
+            if (ev)
+                (void)hipEventDestroy(ev);
+        if (stream)
+            (void)hipStreamDestroy(stream);
+        return RTX_ERR_DEVICE;
+    }
+    c->numCUs = prop.multiProcessorCount;
+    c->ownStream = c->stream = stream;
+    c->ev0 = events[0], c->ev1 = events[1], c->evSwitch = events[2];
+    Arena& h = c->heap;
+    h.tickets = static_cast<uint32_t*>(mem[0]);
+    h.stats = reinterpret_cast<unsigned long long*>(h.tickets + kTicketBytes / sizeof(uint32_t));
+    h.jump = static_cast<uint32_t*>(mem[1]);
+    h.jumpMaxDim = kJumpMaxDim, h.jumpMaxSamples = kJumpMaxSamples;
+    h.blockCost = static_cast<uint32_t*>(mem[2]);
+    h.blockOrder = static_cast<uint32_t*>(mem[3]);
+    h.blockClass = static_cast<uint8_t*>(mem[4]);
+    h.classTable = static_cast<uint32_t*>(mem[5]);
+    h.queueBounds = h.classTable + size_t(kCostClasses) * (kMaxOrderedBlocks / 64);
+    h.maxBlocks = uint32_t(kMaxOrderedBlocks);
+    c->fixedBase = fixedBase;
+    if (fixedBase) {
+        Arena& x = c->fixed;
+        x.tickets = reinterpret_cast<uint32_t*>(fixedBase + kFixedTickets);
+        x.stats = reinterpret_cast<unsigned long long*>(x.tickets + kTicketBytes / sizeof(uint32_t));
+        x.queueBounds = reinterpret_cast<uint32_t*>(fixedBase + kFixedBounds);
+        x.jump = reinterpret_cast<uint32_t*>(fixedBase + kFixedJump);
+        x.jumpMaxDim = kFixedMaxDim, x.jumpMaxSamples = kFixedMaxSamples;
+        x.blockCost = reinterpret_cast<uint32_t*>(fixedBase + kFixedCost);
+        x.blockOrder = reinterpret_cast<uint32_t*>(fixedBase + kFixedOrder);
+        x.blockClass = fixedBase + kFixedClass;
+        x.classTable = reinterpret_cast<uint32_t*>(fixedBase + kFixedTable);
+        x.maxBlocks = kFixedMaxBlocks;
+    }
+    c->slot = slot;
+    c->device = device;
+    return RTX_OK;
+}
+
 } // namespace
 
-// =================================================================== ABI ====
 extern "C" {
 
 const char* rtx_last_error(void) { return g_err; }
@@ -3370,70 +3516,28 @@ int rtx_init(int device)
     }
     HIP_TRY(hipSetDevice(device));
     std::lock_guard<std::mutex> lock(g_ctxMutex);
-    DeviceCtx* c = &g_ctxs[device];
-    if (c->device < 0) {
-        // everything is made in locals and committed at the end, so that a failure
-        // halfway leaves nothing behind and a later call starts from scratch
-        hipStream_t stream = nullptr;
-        hipEvent_t events[3] = {};
-        void* mem[6] = {};
-        const size_t bytes[6] = { kTicketBytes + kStatBytes, // one allocation: cleared together
-            (2 * size_t(kJumpMaxDim) + kJumpMaxSamples) * sizeof(uint32_t), (size_t(kMaxOrderedBlocks) + 64) * sizeof(uint32_t),
-            size_t(kMaxOrderedBlocks) * sizeof(uint32_t), size_t(kMaxOrderedBlocks) + 4, size_t(kCostClasses) * (kMaxOrderedBlocks / 64) * sizeof(uint32_t) + 256 };
-        hipDeviceProp_t prop;
-        unsigned char* fixedBase = nullptr;
-        hipError_t e = hipGetDeviceProperties(&prop, device);
-        if (e == hipSuccess)
-            e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-        for (int i = 0; i < 3 && e == hipSuccess; i++)
-            e = hipEventCreate(&events[i]);
-        for (int i = 0; i < 6 && e == hipSuccess; i++)
-            e = hipMalloc(&mem[i], bytes[i]);
-        // this GPU's copy of the file-scope array (each device holds its own, at its own address)
-        if (e == hipSuccess)
-            e = hipGetSymbolAddress(reinterpret_cast<void**>(&fixedBase), HIP_SYMBOL(scratch));
-        if (e != hipSuccess) {
-            setErr("rtx_init(%d) failed: %s", device, hipGetErrorString(e));
-            for (void* m : mem)
-                if (m)
-                    (void)hipFree(m);
-            for (hipEvent_t ev : events)
-                if (ev)
-                    (void)hipEventDestroy(ev);
-            if (stream)
-                (void)hipStreamDestroy(stream);
-            return RTX_ERR_DEVICE;
-        }
-        c->numCUs = prop.multiProcessorCount;
-        c->ownStream = c->stream = stream;
-        c->ev0 = events[0], c->ev1 = events[1], c->evSwitch = events[2];
-        Arena& h = c->heap;
-        h.tickets = static_cast<uint32_t*>(mem[0]);
-        h.stats = reinterpret_cast<unsigned long long*>(h.tickets + kTicketBytes / sizeof(uint32_t));
-        h.jump = static_cast<uint32_t*>(mem[1]);
-        h.jumpMaxDim = kJumpMaxDim, h.jumpMaxSamples = kJumpMaxSamples;
-        h.blockCost = static_cast<uint32_t*>(mem[2]);
-        h.blockOrder = static_cast<uint32_t*>(mem[3]);
-        h.blockClass = static_cast<uint8_t*>(mem[4]);
-        h.classTable = static_cast<uint32_t*>(mem[5]);
-        h.queueBounds = h.classTable + size_t(kCostClasses) * (kMaxOrderedBlocks / 64);
-        h.maxBlocks = uint32_t(kMaxOrderedBlocks);
-        c->fixedBase = fixedBase;
-        Arena& x = c->fixed;
-        x.tickets = reinterpret_cast<uint32_t*>(fixedBase + kFixedTickets);
-        x.stats = reinterpret_cast<unsigned long long*>(x.tickets + kTicketBytes / sizeof(uint32_t));
-        x.queueBounds = reinterpret_cast<uint32_t*>(fixedBase + kFixedBounds);
-        x.jump = reinterpret_cast<uint32_t*>(fixedBase + kFixedJump);
-        x.jumpMaxDim = kFixedMaxDim, x.jumpMaxSamples = kFixedMaxSamples;
-        x.blockCost = reinterpret_cast<uint32_t*>(fixedBase + kFixedCost);
-        x.blockOrder = reinterpret_cast<uint32_t*>(fixedBase + kFixedOrder);
-        x.blockClass = fixedBase + kFixedClass;
-        x.classTable = reinterpret_cast<uint32_t*>(fixedBase + kFixedTable);
-        x.maxBlocks = kFixedMaxBlocks;
-        c->device = device;
-    }
+    DeviceCtx* c = &g_ctxs[device][0];
+    if (int rc = initCtx(c, device, 0))
+        return rc;
     g_ctx = c;
     g_err[0] = 0;
+    return RTX_OK;
+}
+
+int rtx_select_slot(int slot)
+{
+    if (int rc = checkCtx(nullptr))
+        return rc;
+    if (slot < 0 || slot >= kSlots) {
+        setErr("rtx_select_slot: slot %d out of range (0..%d)", slot, kSlots - 1);
+        return RTX_ERR_INVALID;
+    }
+    const int device = g_ctx->device;
+    std::lock_guard<std::mutex> lock(g_ctxMutex);
+    DeviceCtx* c = &g_ctxs[device][slot];
+    if (int rc = initCtx(c, device, slot))
+        return rc;
+    g_ctx = c;
     return RTX_OK;
 }
 
@@ -4101,6 +4205,10 @@ int rtx_render_device_static(const rtx_scene* scene, const rtx_camera* cam, cons
         setErr("rtx_render_device_static: NULL argument");
         return RTX_ERR_INVALID;
     }
+    if (g_ctx->slot != 0) {
+        setErr("rtx_render_device_static: the fixed workspace belongs to frame slot 0 (this thread has selected slot %d)", g_ctx->slot);
+        return RTX_ERR_INVALID;
+    }
     return renderImpl(scene, cam, f, p, dOut, false, stats, t0, true);
 }
 
@@ -4235,6 +4343,17 @@ int rtx_detile_device(const float* dAllTiles, const rtx_render_params* p, float*
     return RTX_OK;
 }
 
+int rtx_streams_overlap(void* hipStreamA, void* hipStreamB)
+{
+    if (int rc = checkCtx(nullptr))
+        return rc;
+    if (!hipStreamA || !hipStreamB) {
+        setErr("rtx_streams_overlap: NULL stream");
+        return RTX_ERR_INVALID;
+    }
+    return streamsOverlap(static_cast<hipStream_t>(hipStreamA), static_cast<hipStream_t>(hipStreamB));
+}
+
 int rtx_set_stream(void* hipStream)
 {
     if (int rc = checkCtx(nullptr))
@@ -4243,9 +4362,9 @@ int rtx_set_stream(void* hipStream)
     std::lock_guard<std::mutex> launchLock(c->launch);
     const hipStream_t next = hipStream ? static_cast<hipStream_t>(hipStream) : c->ownStream;
     if (next != c->stream) {
-        // The work counters, the block order and the other per-device buffers are shared by
-        // every call on this GPU: what is still queued on the old stream must have finished
-        // with them before anything queued on the new stream touches them.
+        // The work counters, the block order and the other working buffers are shared by
+        // every call in this frame slot: what is still queued on the old stream must have
+        // finished with them before anything queued on the new stream touches them.
         HIP_TRY(hipEventRecord(c->evSwitch, c->stream));
         HIP_TRY(hipStreamWaitEvent(next, c->evSwitch, 0));
         c->stream = next;

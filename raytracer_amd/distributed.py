@@ -75,9 +75,9 @@ def gather_tiles(local_tiles, dst=0, out=None):
 
 
 class FramePipeline:
-    """Double-buffered frame assembly: the gather of frame i runs on the
-    collective's own stream while frame i + 1 is being rendered, and frame i is
-    scattered into the Screen-layout image once frame i + 1 has been queued.
+    """Pipelined frame assembly: the gather of frame i runs on the collective's
+    own stream while frame i + 1 is being rendered, and frame i is scattered into
+    the Screen-layout image once frame i + 1 has been queued.
 
         pipe = FramePipeline(make_buffer, render, assemble)
         for _ in range(n): pipe.submit()
@@ -88,44 +88,60 @@ class FramePipeline:
     only) scatters the gathered rank-major stack.  Every frame submitted is
     gathered and assembled, in order; drain() finishes the last one.  With a
     backend that cannot take the tensors as they are (gloo and GPU tensors) the
-    frames are gathered one after the other through gather_tiles."""
+    frames are gathered one after the other through gather_tiles.
 
-    def __init__(self, make_buffer, render, assemble, dst=0):
+    `slots` > 1 keeps that many frames in flight on the GPU: frame i is rendered,
+    gathered and assembled in slot i % slots, and `enter(slot)` must return a
+    context manager that makes the slot current for the calls inside it (the
+    library's frame slot, rtx_select_slot, and the stream the collective orders
+    itself against).  Frames of different slots run on the GPU at the same time;
+    within a slot they follow one another."""
+
+    def __init__(self, make_buffer, render, assemble, dst=0, slots=1, enter=None):
+        import contextlib
         import torch
         import torch.distributed as dist
         self.render, self.assemble, self.dst = render, assemble, dst
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.tiles = [make_buffer(), make_buffer()]
+        self.slots = max(1, int(slots))
+        self.enter = enter if enter is not None else (lambda slot: contextlib.nullcontext())
+        self.nbuf = max(2, self.slots)
+        self.tiles = [make_buffer() for _ in range(self.nbuf)]
         t = self.tiles[0]
         self.overlapped = not (t.is_cuda and dist.get_backend() == "gloo")
-        self.stacks = [torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if self.rank == dst else None for _ in range(2)]
-        self.pending = None   # (work, buffer index) of the gather in flight
+        self.stacks = [torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if self.rank == dst else None for _ in range(self.nbuf)]
+        self.pending = None   # (work, buffer index, slot) of the gather in flight
         self.frames = 0
 
     def _finish(self):
         if self.pending is None:
             return
-        work, k = self.pending
+        work, k, slot = self.pending
         self.pending = None
-        if work is not None:
-            work.wait()       # a device-side wait under the nccl backend: the host does not block
-        if self.rank == self.dst:
-            self.assemble(self.stacks[k])
+        with self.enter(slot):
+            if work is not None:
+                work.wait()       # a device-side wait under the nccl backend: the host does not block
+            if self.rank == self.dst:
+                self.assemble(self.stacks[k])
 
     def submit(self):
         import torch.distributed as dist
-        k = self.frames & 1
+        k, slot = self.frames % self.nbuf, self.frames % self.slots
         self.frames += 1
-        self.render(self.tiles[k])
+        with self.enter(slot):
+            self.render(self.tiles[k])
+            if not self.overlapped:
+                gather_tiles(self.tiles[k], dst=self.dst, out=self.stacks[k])
+                work = None
+            else:
+                outs = list(self.stacks[k].unbind(0)) if self.rank == self.dst else None
+                work = dist.gather(self.tiles[k], outs, dst=self.dst, async_op=True)
         if not self.overlapped:
-            gather_tiles(self.tiles[k], dst=self.dst, out=self.stacks[k])
-            self.pending = (None, k)
+            self.pending = (None, k, slot)
             self._finish()
             return
-        outs = list(self.stacks[k].unbind(0)) if self.rank == self.dst else None
-        work = dist.gather(self.tiles[k], outs, dst=self.dst, async_op=True)
         self._finish()        # the frame before this one: its gather has had this frame's render to hide behind
-        self.pending = (work, k)
+        self.pending = (work, k, slot)
 
     def drain(self):
         self._finish()

@@ -48,8 +48,27 @@ def hip_lib():
         lib.rtx_detile_device.argtypes = [vp, C.POINTER(abi.RenderParams), vp]
         lib.rtx_tiles_per_rank.argtypes = [C.POINTER(abi.RenderParams)]
         lib.rtx_set_stream.argtypes = [vp]
+        lib.rtx_select_slot.argtypes = [C.c_int]
+        lib.rtx_streams_overlap.argtypes = [vp, vp]
         _hip = lib
     return _hip
+
+
+def concurrent_streams(n, device, tries=16):
+    """`n` torch streams on `device` whose kernels run at the same time (no two on the same
+    hardware queue, rtx_streams_overlap), for frames in flight in as many frame slots.  Fewer
+    are returned when the runtime has no more queues to offer.  rtx_init must have been called."""
+    import torch
+    lib = hip_lib()
+    picked, kept = [torch.cuda.Stream(device=device)], []
+    while len(picked) < n and tries > 0:
+        tries -= 1
+        s = torch.cuda.Stream(device=device)
+        verdicts = [lib.rtx_streams_overlap(vp(p.cuda_stream), vp(s.cuda_stream)) for p in picked]
+        if any(v < 0 for v in verdicts):
+            raise RuntimeError(lib.rtx_last_error().decode())
+        (picked if all(v == 1 for v in verdicts) else kept).append(s)
+    return picked
 
 
 def host_lib():

@@ -37,9 +37,11 @@ def _worker(rank, world, port, width, height, tile, out_path):
     dist.destroy_process_group()
 
 
-def _pipeline_worker(rank, world, port, width, height, tile, out_path):
-    """Five different frames through the double-buffered pipeline: every one must
-    come out assembled, in order, although each gather overlaps the next render."""
+def _pipeline_worker(rank, world, port, width, height, tile, out_path, slots=1):
+    """Five different frames through the pipeline: every one must come out assembled, in
+    order, although each gather overlaps the next render.  With `slots` frames in flight
+    frame i must be rendered and assembled inside slot i % slots."""
+    import contextlib
     import torch
     import torch.distributed as dist
     from raytracer_amd.distributed import FramePipeline
@@ -51,16 +53,32 @@ def _pipeline_worker(rank, world, port, width, height, tile, out_path):
     state = {"next": 0}
     rebuilt = []
 
+    current, rendered_in, assembled_in = [None], [], []
+
+    @contextlib.contextmanager
+    def enter(slot):
+        assert current[0] is None
+        current[0] = slot
+        yield
+        current[0] = None
+
     def render(tiles):
+        rendered_in.append(current[0])
         tiles.copy_(torch.from_numpy(extract_tiles(frames[state["next"]], tile, rank, world)))
         state["next"] += 1
 
-    pipe = FramePipeline(lambda: torch.zeros((per, tile, tile, 3), dtype=torch.float32), render,
-                         lambda stack: rebuilt.append(assemble_tiles(stack.numpy().copy(), width, height, tile, world)))
+    def assemble(stack):
+        assembled_in.append(current[0])
+        rebuilt.append(assemble_tiles(stack.numpy().copy(), width, height, tile, world))
+
+    pipe = FramePipeline(lambda: torch.zeros((per, tile, tile, 3), dtype=torch.float32), render, assemble, slots=slots, enter=enter)
     for _ in frames:
         pipe.submit()
     pipe.drain()
+    want_slots = [i % slots for i in range(len(frames))]
+    assert rendered_in == want_slots, rendered_in
     if rank == 0:
+        assert assembled_in == want_slots, assembled_in
         np.save(out_path, np.array([len(rebuilt) == len(frames)] + [np.array_equal(a, b) for a, b in zip(rebuilt, frames)]))
     else:
         assert not rebuilt
@@ -68,10 +86,11 @@ def _pipeline_worker(rank, world, port, width, height, tile, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_frame_pipeline_assembles_every_frame_in_order(tmp_path):
+@pytest.mark.parametrize("slots", [1, 2, 3])
+def test_two_rank_frame_pipeline_assembles_every_frame_in_order(tmp_path, slots):
     import torch.multiprocessing as mp
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_pipeline_worker, args=(2, _free_port(), 100, 70, 16, out), nprocs=2, join=True)
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), 100, 70, 16, out, slots), nprocs=2, join=True)
     ok = np.load(out)
     assert len(ok) == 6 and ok.all()
 

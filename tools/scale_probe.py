@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--slots", type=int, default=1, help="frames in flight (rtx_select_slot): frame i is queued in slot i %% slots on that slot's stream")
     args = ap.parse_args()
     import torch
     from raytracer_amd import abi, engine
@@ -32,21 +33,29 @@ def main():
     gpu = engine.GpuEngine(dragon_scene(), f)
     cam = engine.device_camera(make_camera(), W, H)
     dev = torch.device("cuda", 0)
-    stream = torch.cuda.Stream(device=dev)
+    streams = engine.concurrent_streams(args.slots, dev)
+    args.slots = len(streams)
+    for k in reversed(range(args.slots)):
+        assert hip.rtx_select_slot(k) == 0
+        assert hip.rtx_set_stream(C.c_void_p(streams[k].cuda_stream)) == 0
+    stream = streams[0]
     torch.cuda.set_stream(stream)
-    assert hip.rtx_set_stream(C.c_void_p(stream.cuda_stream)) == 0
     frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     for world in [int(w) for w in args.worlds.split(",")]:
         worst = 0.0
         for rank in range(world):
             rp = make_params(W, H, driver=abi.DRIVER_MRAYS, samples=16, tile_size=args.tile, tile_rank=rank, tile_world=world)
             per = hip.rtx_tiles_per_rank(C.byref(rp))
-            tiles = torch.zeros((per, args.tile, args.tile, 3), dtype=torch.float32, device=dev)
+            tiles = [torch.zeros((per, args.tile, args.tile, 3), dtype=torch.float32, device=dev) for _ in range(args.slots)]
+            n = [0]
 
             def step():
-                rc = hip.rtx_render_tiles_device(gpu.device_scene(), C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(tiles.data_ptr()), None)
+                k = n[0] % args.slots
+                n[0] += 1
+                assert hip.rtx_select_slot(k) == 0
+                rc = hip.rtx_render_tiles_device(gpu.device_scene(), C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(tiles[k].data_ptr()), None)
                 assert rc == 0, hip.rtx_last_error()
-            for _ in range(3):
+            for _ in range(3 * args.slots):
                 step()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,7 +63,12 @@ def main():
             e0.record(stream)
             for _ in range(args.steps):
                 step()
+            for k in range(1, args.slots):
+                e = torch.cuda.Event()
+                e.record(streams[k])
+                stream.wait_event(e)
             e1.record(stream)
+            hip.rtx_select_slot(0)
             host = time.perf_counter() - t0
             torch.cuda.synchronize()
             dev_ms = e0.elapsed_time(e1) / args.steps
