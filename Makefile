@@ -8,7 +8,9 @@ CXX      ?= g++
 ARCH     ?= gfx950
 # -ffp-contract=off: no fused multiply-add on host or device; results must be
 # bit-identical to the reference's plain fp32 arithmetic
-HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -Wno-pass-failed -std=c++17 -fPIC -ffp-contract=off -Iinclude -Iraytracer_amd/csrc
+# -fno-slp-vectorize: the compiler's own pairing of fp32 operations into v_pk_* costs more in register
+# shuffles than a packed instruction saves on gfx950 (4.3 cycles against 2 x 2.6): frames 3-5 % faster without
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -Wno-pass-failed -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Iinclude -Iraytracer_amd/csrc
 CXXFLAGS ?= -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude -Iraytracer_amd/host -pthread
 
 HOST_SRC := $(wildcard raytracer_amd/host/*.cpp)

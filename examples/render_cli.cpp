@@ -113,6 +113,8 @@ int main(int argc, char** argv)
         for (size_t index = 0; index < config.cameras.size(); index++)
             workers.emplace_back([&, index] {
                 try {
+                    // a frame slot per thread: the cameras' frames share the GPU instead of taking turns
+                    rt::selectFrameSlot(int(index % RTX_FRAME_SLOTS));
                     const rt::CameraConfig& cc = config.cameras[index];
                     rt::Screen screen(config.windowSize, false);
                     screen.clear(rt::vec3(0.0f, 0.0f, 0.0f));

@@ -1536,9 +1536,10 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
 // frame (walkPath: radiance rays only, no pixel is written); 5: MODE 0 with every ray walking the
 // tree on its own
 template <int STACK, bool COUNT, int MODE>
-__global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE == 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A)
+__global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A)
 {
-    constexpr bool FULL = MODE != 0 && MODE != 5;
+    constexpr bool FULL = MODE >= 1 && MODE <= 4;
+    constexpr bool BLUR = FULL || MODE >= 6; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
     __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
     extern __shared__ int32_t sFan[]; // MODE 4: fanLevels * fan size * kBlock distances, then as many triangle records
@@ -1658,7 +1659,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE == 5) ? RTX_LEAN_WA
                         d = normalize(focalPoint - o);
                     } break;
                     case RTX_DRIVER_MOTION_BLUR:
-                        if (FULL) {
+                        if (BLUR) {
                             // src/render.cpp:203-247: the samples extrapolate from the current
                             // pose by the pose change since the previous call
                             uint64_t rng = driverRngState(A, x, y, pixelIndex, sample, 1);
@@ -1687,7 +1688,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE == 5) ? RTX_LEAN_WA
                 walkPath<STACK, COUNT>(A, st, fan, o, d, active, key, storeIndex * uint32_t(A.samples) + uint32_t(sample), lc);
                 continue; // (the pixel is written by resolveKernel)
             }
-            const V3 c = MODE == 4 ? mk(0, 0, 0) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0>(A, st, o, d, active, lc);
+            const V3 c = MODE == 4 ? mk(0, 0, 0) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
             } else if (!anyLane(!(c.x == 0.f && c.y == 0.f && c.z == 0.f))) {
@@ -2437,33 +2438,22 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode, size_t
         const int grid = std::max(1, std::min<int>(gridFor(c, k, dynamicLds), int((A.work.nChunks + 3) / 4)));    \
         hipLaunchKernelGGL((renderKernel<STACK, CNT, MODEV>), dim3(grid), dim3(kBlock), dynamicLds, c->stream, A); \
     }
-    if (count) {
-        if (mode == 5)
-            RTX_LAUNCH(true, 5)
-        else if (mode == 4)
-            RTX_LAUNCH(true, 4)
-        else if (mode == 3)
-            RTX_LAUNCH(true, 3)
-        else if (mode == 2)
-            RTX_LAUNCH(true, 2)
-        else if (mode == 1)
-            RTX_LAUNCH(true, 1)
-        else
-            RTX_LAUNCH(true, 0)
-    } else {
-        if (mode == 5)
-            RTX_LAUNCH(false, 5)
-        else if (mode == 4)
-            RTX_LAUNCH(false, 4)
-        else if (mode == 3)
-            RTX_LAUNCH(false, 3)
-        else if (mode == 2)
-            RTX_LAUNCH(false, 2)
-        else if (mode == 1)
-            RTX_LAUNCH(false, 1)
-        else
-            RTX_LAUNCH(false, 0)
+#define RTX_LAUNCH_MODES(CNT)                                                                                     \
+    switch (mode) {                                                                                               \
+    case 7: RTX_LAUNCH(CNT, 7) break;                                                                             \
+    case 6: RTX_LAUNCH(CNT, 6) break;                                                                             \
+    case 5: RTX_LAUNCH(CNT, 5) break;                                                                             \
+    case 4: RTX_LAUNCH(CNT, 4) break;                                                                             \
+    case 3: RTX_LAUNCH(CNT, 3) break;                                                                             \
+    case 2: RTX_LAUNCH(CNT, 2) break;                                                                             \
+    case 1: RTX_LAUNCH(CNT, 1) break;                                                                             \
+    default: RTX_LAUNCH(CNT, 0) break;                                                                            \
     }
+    if (count)
+        RTX_LAUNCH_MODES(true)
+    else
+        RTX_LAUNCH_MODES(false)
+#undef RTX_LAUNCH_MODES
 #undef RTX_LAUNCH
     return RTX_OK;
 }
@@ -2920,8 +2910,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
 
     // the full kernel carries the reflection / transparency / area-light /
     // texture / environment machinery; the lean one is enough otherwise
-    const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || driver == RTX_DRIVER_TRANSPARENCY
-        || driver == RTX_DRIVER_MOTION_BLUR; // per-sample cameras need device trigonometry
+    const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || driver == RTX_DRIVER_TRANSPARENCY;
     // (glossy fans are traced side by side where a wave holds few pixels, i.e. under area
     // lights: with a full wave of paths the lanes' own traversals already run side by side)
     const bool fans = f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1 && A.glossyRays <= kFanMax
@@ -2929,7 +2918,8 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // (the lens samples of the depth-of-field driver make no coherent bundle, and 64 pixels with one
     // sample each share too little of the tree below its top levels: lane by lane; RTX_LEAN_WALK=0/1 overrides)
     const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : driver != RTX_DRIVER_DOF && A.lanesPerPixel >= 2;
-    const int mode = !full ? (together ? 0 : 5) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
+    // (the motion-blur driver's lean kernels carry the per-sample camera's trigonometry: modes 6 / 7)
+    const int mode = !full ? (driver == RTX_DRIVER_MOTION_BLUR ? (together ? 6 : 7) : (together ? 0 : 5)) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
     A.runIf = nullptr;
     A.defer = Deferred {};
     size_t walkLds = 0;

@@ -38,6 +38,13 @@ void selectDevice(int device)
     t_deviceChosen = true;
 }
 
+void selectFrameSlot(int slot)
+{
+    ensureDevice();
+    if (rtx_select_slot(slot) != RTX_OK)
+        fail("rtx_select_slot");
+}
+
 rtx_features toDeviceFeatures(const Features& f)
 {
     rtx_features o;

@@ -30,6 +30,10 @@ struct RtError : std::runtime_error {
 // Bind the calling thread to a GPU (rtx_init).  BvhInterface's constructor calls
 // selectDevice(0) itself if the thread has not chosen one.
 void selectDevice(int device);
+// The frame slot (0 .. RTX_FRAME_SLOTS - 1) the calling thread's frames are queued in
+// (rtx_select_slot).  Frames of different slots run on the GPU at the same time, which is how
+// threads that each render a camera of their own (src/main.cpp:560-585) share one GPU.
+void selectFrameSlot(int slot);
 
 // Process-wide sampling knobs, globals in the reference: sampleSize
 // (src/light.cpp:14) and numberOfRays (src/shading.cpp:9).

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 out=${1:-/tmp/rtx_isa.s}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-pass-failed -std=c++17 -fPIC -ffp-contract=off -Iinclude -Iraytracer_amd/csrc \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-pass-failed -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Iinclude -Iraytracer_amd/csrc \
   --cuda-device-only -S $RTX_DEFS -o "$out" raytracer_amd/csrc/rtx_hip.hip 2>/dev/null
 python3 - "$out" <<'PY'
 import re, sys

@@ -19,7 +19,7 @@
 typedef float F2 __attribute__((ext_vector_type(2)));
 
 enum Kind {
-    K_MUL = 0, K_ADD, K_FMA, K_PK_MUL, K_PK_ADD, K_PK_FMA, K_CNDMASK, K_MINMAX, K_MIN3, K_CMP_CNDMASK, K_DIV, K_SQRT, K_MOV, K_INT, K_MIX, K_COUNT
+    K_MUL = 0, K_ADD, K_FMA, K_PK_MUL, K_PK_ADD, K_PK_FMA, K_CNDMASK, K_MINMAX, K_MIN3, K_CMP_CNDMASK, K_DIV, K_SQRT, K_MOV, K_INT, K_MAX_I32, K_MAX3_I32, K_CMP_F32, K_CMP_I32, K_CNDMASK_S, K_MIX, K_COUNT
 };
 
 constexpr int kBody = 64;
@@ -75,6 +75,19 @@ __global__ void __launch_bounds__(256) valuKernel(int iters, float seed, unsigne
             REP16(asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
         } else if (KIND == K_INT) {
             REP16(asm volatile("v_xor_b32 %0, %0, %1\n v_add_u32 %1, %1, %0\n v_lshlrev_b32 %0, 1, %0\n v_ashrrev_i32 %1, 1, %1" : "+v"(i0), "+v"(i1));)
+        } else if (KIND == K_MAX_I32) {
+            REP16(asm volatile("v_max_i32 %0, %0, %4\n v_min_i32 %1, %1, %4\n v_max_u32 %2, %2, %4\n v_min_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
+        } else if (KIND == K_MAX3_I32) {
+            REP16(asm volatile("v_max3_i32 %0, %0, %4, %5\n v_min3_i32 %1, %1, %4, %5\n v_max3_u32 %2, %2, %4, %5\n v_min3_u32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
+        } else if (KIND == K_CMP_F32) {
+            // compares alone, each into a scalar register pair of its own (nothing reads them)
+            REP16(asm volatile("v_cmp_gt_f32 s[10:11], %0, %4\n v_cmp_lt_f32 s[12:13], %1, %4\n v_cmp_ngt_f32 s[14:15], %2, %4\n v_cmp_nlt_f32 vcc, %3, %4" : : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b) : "vcc", "s10", "s11", "s12", "s13", "s14", "s15");)
+        } else if (KIND == K_CMP_I32) {
+            REP16(asm volatile("v_cmp_gt_i32 s[10:11], %0, %4\n v_cmp_lt_i32 s[12:13], %1, %4\n v_cmp_gt_u32 s[14:15], %2, %4\n v_cmp_lt_u32 vcc, %3, %4" : : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b) : "vcc", "s10", "s11", "s12", "s13", "s14", "s15");)
+        } else if (KIND == K_CNDMASK_S) {
+            // selects on a mask in a scalar register pair that nothing rewrites, four independent chains
+            asm volatile("v_cmp_gt_f32 s[10:11], %0, %1\n s_nop 4" : : "v"(a0), "v"(b) : "s10", "s11");
+            REP16(asm volatile("v_cndmask_b32 %0, %0, %4, s[10:11]\n v_cndmask_b32 %1, %1, %4, s[10:11]\n v_cndmask_b32 %2, %2, %4, s[10:11]\n v_cndmask_b32 %3, %3, %4, s[10:11]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "s10", "s11");)
         } else if (KIND == K_MIX) {
             // Proportions of the traversal loop of the frame kernel (one trip = a node's two
             // boxes or one triangle; static count over both paths of its ISA): per 73
@@ -138,7 +151,7 @@ extern "C" {
 const char* valu_peak_kind_name(int kind)
 {
     static const char* names[K_COUNT] = { "v_mul_f32", "v_add_f32", "v_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_cndmask_b32", "v_min/max_f32", "v_min3/max3_f32",
-        "v_cmp+v_cndmask", "IEEE divide (11 instr)", "IEEE sqrt", "v_mov_b32", "integer xor/add/shift", "traversal-loop mix" };
+        "v_cmp+v_cndmask", "IEEE divide (11 instr)", "IEEE sqrt", "v_mov_b32", "integer xor/add/shift", "v_min/max_i32/u32", "v_min3/max3_i32/u32", "v_cmp_f32 alone", "v_cmp_i32/u32 alone", "v_cndmask_b32 (sgpr mask)", "traversal-loop mix" };
     return kind >= 0 && kind < K_COUNT ? names[kind] : "?";
 }
 int valu_peak_kinds(void) { return K_COUNT; }
@@ -177,7 +190,7 @@ int valu_peak_run(int kind, int wavesPerSimd, int iters, double* out)
 #define CASE(K) case K: if (e == hipSuccess) e = launch<K>(grid, iters, cycles, sink, nullptr); break;
         switch (kind) {
             CASE(K_MUL) CASE(K_ADD) CASE(K_FMA) CASE(K_PK_MUL) CASE(K_PK_ADD) CASE(K_PK_FMA) CASE(K_CNDMASK) CASE(K_MINMAX) CASE(K_MIN3) CASE(K_CMP_CNDMASK) CASE(K_DIV)
-            CASE(K_SQRT) CASE(K_MOV) CASE(K_INT) CASE(K_MIX)
+            CASE(K_SQRT) CASE(K_MOV) CASE(K_INT) CASE(K_MAX_I32) CASE(K_MAX3_I32) CASE(K_CMP_F32) CASE(K_CMP_I32) CASE(K_CNDMASK_S) CASE(K_MIX)
         }
 #undef CASE
         if (e == hipSuccess)
