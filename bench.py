@@ -440,7 +440,7 @@ def main():
                     achieved = valu_instr / (kernel_ms * 1e-3) / 1e9
                     out["roofline_valu"] = {"bound": "valu issue", "achieved": round(achieved, 1), "peak": round(vp["chip_ginstr_s"], 1), "unit": "G wave-instr/s",
                                             "frac": round(achieved / vp["chip_ginstr_s"], 4), "valu_instr_per_launch": int(valu_instr),
-                                            "peak_is": "measured now on this GPU: the traversal loop's instruction mix (tools/valu_peak.hip) at the kernel's 4 waves per SIMD",
+                                            "peak_is": "measured now on this GPU: the instruction mix of the kernel's traversal loop (static proportions of its ISA, tools/valu_peak.hip) at the kernel's 4 waves per SIMD",
                                             "peak_instr_per_cycle_per_simd": round(vp["ipc"], 4), "peak_v_mul_f32_instr_per_cycle_per_simd": round(vp["ipc_mul"], 4),
                                             "clock_mhz": round(vp["clock_mhz"])}
             if cb is not None:

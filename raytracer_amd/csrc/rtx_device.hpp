@@ -515,6 +515,17 @@ RTX_DEV void traverseBvh(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, flo
 // (the compiler's own ballot on a condition: no detour through a 0 / 1 integer per lane)
 RTX_DEV uint64_t laneMask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 RTX_DEV bool anyLane(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; }
+// m's bit for this lane ? a : b, for a wave mask that scalar instructions made (the result of a
+// vote combined with others: the compiler has no per-lane form of it, and rebuilding one costs
+// more than this select).  The mask must not be the untouched result of a vector compare: the
+// select would read it before the hardware's wait states for such a pair have passed.
+RTX_DEV float selectByMask(uint64_t m, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+RTX_DEV int selectByMask(uint64_t m, int a, int b) { return __float_as_int(selectByMask(m, __int_as_float(a), __int_as_float(b))); }
 typedef float NF4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const NF4 UniformF4; // constant address space: uniform addresses load through the scalar cache
 RTX_DEV const UniformF4* uniformRecords(const float4* p) { return (const UniformF4*)(uintptr_t)p; }
@@ -589,21 +600,24 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
     const float inf = __builtin_inff();
     int sp = 0;
     int32_t cur = __builtin_amdgcn_readfirstlane(sc.waveRoot);
-    bool act = alive;
-    if (!anyLane(act))
+    // Which lanes take part is kept as wave masks (aliveM: still looking for a hit; actM: inside
+    // the current subtree), combined from the votes with scalar instructions: a vote on a
+    // condition put together per lane costs two more vector instructions each time.
+    uint64_t aliveM = laneMask(alive), actM = aliveM;
+    if (!actM)
         return;
     for (;;) {
         if (cur >= 0) {
 #ifdef RTX_PROBE
             tc.waveOuter += (threadIdx.x & 63u) == 0u;
-            tc.outer += act ? 1u : 0u;
+            tc.outer += (actM >> (threadIdx.x & 63u)) & 1u;
 #endif
             const UniformF4* p = nodes + size_t(uint32_t(cur)) * kWaveNodeQuads;
             const NF4 XL = p[0], XH = p[1], YL = p[2], YH = p[3], ZL = p[4], ZH = p[5], R = p[6];
             // (the children's references come with the boxes, not in a second round trip to memory
             // once a child turns out to be entered: the empty statement keeps the load up here)
             asm volatile("" ::"s"(R.x), "s"(R.y), "s"(R.z), "s"(R.w));
-            const float limit = act ? t : -inf; // (a lane that sits this subtree out enters nothing)
+            const float limit = selectByMask(actM, t, -inf); // (a lane that sits this subtree out enters nothing)
             const float k0 = childKey<MODE, ANYSIGN>(XL.x, YL.x, ZL.x, XH.x, YH.x, ZH.x, om, im, limit);
             const float k1 = childKey<MODE, ANYSIGN>(XL.y, YL.y, ZL.y, XH.y, YH.y, ZH.y, om, im, limit);
             float k2 = childKey<MODE, ANYSIGN>(XL.z, YL.z, ZL.z, XH.z, YH.z, ZH.z, om, im, limit);
@@ -616,7 +630,7 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                 k3 = nChildren > 3 ? k3 : inf;
             }
             if (COUNT)
-                tc.boxTests += act ? 4u : 0u;
+                tc.boxTests += uint32_t((actM >> (threadIdx.x & 63u)) & 1u) * 4u;
             const bool h0 = !(limit < k0), h1 = !(limit < k1), h2 = !(limit < k2), h3 = !(limit < k3);
             const uint64_t b0 = laneMask(h0), b1 = laneMask(h1), b2 = laneMask(h2), b3 = laneMask(h3);
             // The children are stored nearest first for this octant: the walk goes on in the
@@ -631,7 +645,7 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                 if (b1 && first < 1)
                     st.pushWave(sp++, r1, h1 ? k1 : inf);
                 cur = first == 0 ? r0 : first == 1 ? r1 : first == 2 ? r2 : r3;
-                act = !(limit < (first == 0 ? k0 : first == 1 ? k1 : first == 2 ? k2 : k3));
+                actM = first == 0 ? b0 : first == 1 ? b1 : first == 2 ? b2 : b3; // (the lanes that enter it)
                 continue;
             }
         } else {
@@ -640,33 +654,37 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                 const bool last = __float_as_int(A.w) < 0; // (top bit of the id word)
 #ifdef RTX_PROBE
                 tc.waveInner += (threadIdx.x & 63u) == 0u;
-                tc.inner += act ? 1u : 0u;
+                tc.inner += (actM >> (threadIdx.x & 63u)) & 1u;
 #endif
                 if (COUNT)
-                    tc.triTests += act ? 1u : 0u;
-                // the plane part of triangleTest
+                    tc.triTests += uint32_t((actM >> (threadIdx.x & 63u)) & 1u);
+                // the plane part of triangleTest.  (Its `dn == 0` rejection needs no test of its own:
+                // the quotient is then an infinity or a NaN, which fails one of the two comparisons.)
                 const float dn = P.x * d.x + P.y * d.y + P.z * d.z;
                 const float no = P.x * o.x + P.y * o.y + P.z * o.z;
                 const float th = (P.w - no) / dn;
-                bool ok = act && !(dn == 0.f) && !(th <= 0.f) && (th < t);
-                if (anyLane(ok)) {
+                const bool behind = th <= 0.f, nearer = th < t;
+                const uint64_t okM = actM & ~laneMask(behind) & laneMask(nearer);
+                if (okM) {
                     const V3 n = mk(P.x, P.y, P.z);
                     const V3 pt = o + th * d;
                     const V3 e0 = pt - mk(A.x, A.y, A.z), e1 = pt - mk(B.x, B.y, B.z);
                     const float alpha = dot(n, cross(mk(E1.x, E1.y, E1.z), e1));
                     const float beta = dot(n, cross(e0, mk(E0.x, E0.y, E0.z)));
                     const float gamma = dot(n, cross(mk(C.x, C.y, C.z), e0));
-                    ok = ok && !(alpha < 0 || beta < 0 || gamma < 0);
-                    if (ok) {
-                        t = th;
-                        bestK = int(k);
-                        if (EARLY && t < tStop) {
-                            alive = false;
-                            act = false;
+                    const bool outside = alpha < 0 || beta < 0 || gamma < 0;
+                    const uint64_t hitM = okM & ~laneMask(outside);
+                    if (hitM) {
+                        t = selectByMask(hitM, th, t);
+                        bestK = selectByMask(hitM, int(k), bestK);
+                        if (EARLY) {
+                            const uint64_t stopM = hitM & laneMask(th < tStop);
+                            aliveM &= ~stopM;
+                            actM &= ~stopM;
                         }
                     }
                 }
-                return last || !anyLane(act);
+                return last || !actM;
             };
             // Two whole records per round trip to memory (a leaf's triangles lie one behind the
             // other): the walk of a wave that has the SIMD to itself -- the long units a frame ends
@@ -688,8 +706,8 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
         while (sp > 0) {
             const float key = st.waveKey(--sp);
             const int32_t ref = st.waveRef(sp); // (read with the key, not after the vote)
-            act = alive && !(t < key);
-            if (anyLane(act)) {
+            actM = aliveM & ~laneMask(t < key);
+            if (actM) {
                 cur = ref;
                 have = true;
                 break;

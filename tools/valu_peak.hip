@@ -89,35 +89,39 @@ __global__ void __launch_bounds__(256) valuKernel(int iters, float seed, unsigne
             asm volatile("v_cmp_gt_f32 s[10:11], %0, %1\n s_nop 4" : : "v"(a0), "v"(b) : "s10", "s11");
             REP16(asm volatile("v_cndmask_b32 %0, %0, %4, s[10:11]\n v_cndmask_b32 %1, %1, %4, s[10:11]\n v_cndmask_b32 %2, %2, %4, s[10:11]\n v_cndmask_b32 %3, %3, %4, s[10:11]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "s10", "s11");)
         } else if (KIND == K_MIX) {
-            // Proportions of the traversal loop of the frame kernel (one trip = a node's two
-            // boxes or one triangle; static count over both paths of its ISA): per 73
-            // instructions 9 packed multiplies, 10 packed adds, 5 multiplies, 5 adds / subs,
-            // 4 fused multiply-adds + rcp + 2 div_scale + div_fmas + div_fixup (the division
-            // of the plane test), 9 compares each followed by a select, 8 min / max,
-            // 5 moves, 4 integer operations.
+            // Proportions of the frame kernel's traversal loop (the wave-shared walk: one four-wide
+            // node, a leaf's triangle pairs, the pop; static count over its ISA, 323 vector
+            // instructions): per 64 instructions 20 multiplies, 16 adds / subs, 2 fused multiply-adds,
+            // 3 moves, 2 integer operations (the fast kind), and 5 selects, 5 compares, 3 min3 / max3,
+            // 4 lane reads into scalar registers, div_scale + rcp + div_fmas + div_fixup of the plane
+            // test's division (the slow kind).
             asm volatile(
-                "v_pk_mul_f32 %4, %4, %10\n v_pk_add_f32 %5, %5, %10\n v_pk_mul_f32 %6, %6, %10\n v_pk_add_f32 %7, %7, %10\n"
-                "v_pk_mul_f32 %4, %4, %10\n v_pk_add_f32 %5, %5, %10\n v_pk_mul_f32 %6, %6, %10\n v_pk_add_f32 %7, %7, %10\n"
-                "v_pk_mul_f32 %4, %4, %10\n v_pk_add_f32 %5, %5, %10\n v_pk_mul_f32 %6, %6, %10\n v_pk_add_f32 %7, %7, %10\n"
-                "v_pk_mul_f32 %4, %4, %10\n v_pk_add_f32 %5, %5, %10\n v_pk_mul_f32 %6, %6, %10\n v_pk_add_f32 %7, %7, %10\n"
-                "v_pk_mul_f32 %4, %4, %10\n v_pk_add_f32 %5, %5, %10\n v_pk_add_f32 %7, %7, %10\n"
-                "v_mul_f32 %0, %0, %11\n v_add_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n v_mul_f32 %0, %0, %11\n"
-                "v_add_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_add_f32 %3, %3, %11\n v_mul_f32 %0, %0, %11\n v_add_f32 %1, %1, %11\n"
-                "v_div_scale_f32 %2, s[10:11], %0, %0, %1\n v_rcp_f32 %3, %2\n v_div_scale_f32 %2, vcc, %1, %0, %1\n"
-                "v_fma_f32 %3, %3, %11, %2\n v_fma_f32 %2, %3, %11, %2\n v_fma_f32 %3, %2, %11, %3\n v_fma_f32 %2, %3, %11, %2\n"
+                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
+                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
+                "v_mul_f32 %0, %0, %11\n v_add_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_add_f32 %3, %3, %11\n"
+                "v_max3_f32 %0, %0, %11, %1\n v_min3_f32 %2, %2, %11, %3\n"
+                "v_cmp_ngt_f32 s[10:11], %0, %2\n v_cmp_nge_f32 vcc, %11, %0\n"
+                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
+                "v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %1, %1, %3, s[10:11]\n"
+                "v_mul_f32 %0, %0, %11\n v_add_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_add_f32 %3, %3, %11\n"
+                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
+                "v_cmp_nlt_f32 s[12:13], %1, %0\n v_cmp_nlt_f32 s[14:15], %3, %2\n"
+                "v_readlane_b32 s16, %8, 3\n v_readlane_b32 s17, %8, 7\n"
+                "v_mul_f32 %0, %0, %11\n v_add_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_add_f32 %3, %3, %11\n"
+                "v_cndmask_b32 %2, %2, %0, s[12:13]\n v_cndmask_b32 %3, %3, %1, s[14:15]\n"
+                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
+                "v_div_scale_f32 %2, s[10:11], %0, %0, %1\n v_rcp_f32 %3, %2\n"
+                "v_fma_f32 %3, %3, %11, %2\n v_fma_f32 %2, %3, %11, %2\n v_mul_f32 %0, %0, %11\n v_mul_f32 %1, %1, %11\n"
+                "v_cmp_lt_f32 vcc, %1, %0\n"
                 "v_div_fmas_f32 %3, %3, %2, %11\n v_div_fixup_f32 %2, %3, %0, %1\n"
-                "v_cmp_gt_f32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cmp_lt_f32 vcc, %2, %3\n s_nop 1\n v_cndmask_b32 %2, %2, %3, vcc\n"
-                "v_cmp_gt_f32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cmp_lt_f32 vcc, %2, %3\n s_nop 1\n v_cndmask_b32 %2, %2, %3, vcc\n"
-                "v_cmp_gt_f32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cmp_lt_f32 vcc, %2, %3\n s_nop 1\n v_cndmask_b32 %2, %2, %3, vcc\n"
-                "v_cmp_gt_f32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cmp_lt_f32 vcc, %2, %3\n s_nop 1\n v_cndmask_b32 %2, %2, %3, vcc\n"
-                "v_cmp_gt_f32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc\n"
-                "v_max_f32 %0, %0, %11\n v_min_f32 %1, %1, %11\n v_max3_f32 %2, %2, %11, %0\n v_min3_f32 %3, %3, %11, %1\n"
-                "v_max_f32 %0, %0, %11\n v_min_f32 %1, %1, %11\n v_max3_f32 %2, %2, %11, %0\n v_min3_f32 %3, %3, %11, %1\n"
-                "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0\n v_mov_b32 %0, %2\n"
-                "v_xor_b32 %8, %8, %9\n v_add_u32 %9, %9, %8\n v_lshlrev_b32 %8, 1, %8\n v_ashrrev_i32 %9, 1, %9\n"
+                "v_mul_f32 %0, %0, %11\n v_mul_f32 %2, %2, %11\n"
+                "v_max3_f32 %1, %1, %11, %0\n v_cndmask_b32 %3, %3, %2, vcc\n"
+                "v_readlane_b32 s18, %9, 11\n v_readlane_b32 s19, %9, 13\n"
+                "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n"
+                "v_lshl_add_u32 %8, %8, 2, %9\n v_add_u32 %9, %9, %8\n"
                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(i0), "+v"(i1)
                 : "v"(q), "v"(b)
-                : "vcc", "s10", "s11");
+                : "vcc", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19");
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -134,7 +138,7 @@ static int bodyInstructions(int kind)
     case K_CMP_CNDMASK: return 64;     // 32 compares + 32 selects (the s_nop wait states are not VALU instructions)
     case K_DIV: return 6 * 11;
     case K_SQRT: return 66;            // four correctly rounded square roots as hipcc expands them (counted in the ISA)
-    case K_MIX: return 73;             // vector instructions in the mixed body
+    case K_MIX: return 64;             // vector instructions in the mixed body
     default: return kBody;
     }
 }
