@@ -541,10 +541,12 @@ constexpr int kWaveNodeQuads = 8, kWaveTriQuads = 6;
 //                 NaN must fall through the comparisons exactly as in the reference)
 enum BoxMode { BOX_MIRRORED = 0, BOX_OUTSIDE = 1, BOX_LITERAL = 2 };
 
-// The visit rule of one child as ONE number: the key the reference would enter the child
-// with (0 when the origin lies inside, else the slab test's entry distance), or +inf when
-// its slab test misses.  The lane then enters iff !(limit < key), which is the reference's
-// `hit && !(ray.t < first)`; and a key of +inf keeps a lane out for good.
+// The visit rule of one child: the key the reference would enter the child with (0 when the
+// origin lies inside, else the slab test's entry distance) and the wave mask of the lanes that
+// enter it -- those for which the slab test hits and !(limit < key), which is the reference's
+// `hit && !(ray.t < first)`, or whose origin lies inside.  (The mask is put together from the
+// separate comparisons' votes by scalar instructions; folding a miss into the key as +inf
+// first cost a select per child.)  `partM`: the lanes taking part (their limit is finite).
 // Mirrored frame: lo <= hi per axis and im > 0, so t0 = (lo - o) * im <= t1 = (hi - o) * im
 // already (childTestFinite's numbers without the per-axis ordering).
 // With ANYSIGN the lanes' directions need not share the frame's octant: a lane whose direction
@@ -552,8 +554,13 @@ enum BoxMode { BOX_MIRRORED = 0, BOX_OUTSIDE = 1, BOX_LITERAL = 2 };
 // 1/d, an exact negation), and each axis' two products are put in order with min / max, which is
 // childTestFinite's arithmetic on the very same numbers.
 template <int MODE, bool ANYSIGN>
-RTX_DEV float childKeyMirrored(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im)
+RTX_DEV void childVisit(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im, float limit, uint64_t partM, float& key, uint64_t& enterM)
 {
+    if (MODE == BOX_LITERAL) {
+        const bool h = childTest(mk(lox, loy, loz), mk(hix, hiy, hiz), om, im, limit, key);
+        enterM = laneMask(h) & partM; // (the literal test lets an origin inside the box in whatever the limit)
+        return;
+    }
     const float dlx = lox - om.x, dly = loy - om.y, dlz = loz - om.z;
     const float dhx = hix - om.x, dhy = hiy - om.y, dhz = hiz - om.z;
     float t0x = dlx * im.x, t0y = dly * im.y, t0z = dlz * im.z;
@@ -563,27 +570,18 @@ RTX_DEV float childKeyMirrored(float lox, float loy, float loz, float hix, float
         t1x = fmaxf(t0x, t1x), t1y = fmaxf(t0y, t1y), t1z = fmaxf(t0z, t1z);
         t0x = ax, t0y = ay, t0z = az;
     }
-    float first = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
+    const float first = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
     const float second = fminf(fminf(t1x, t1y), t1z);
-    const bool miss = first > second;
-    if (first <= 0.0f)
-        first = second;
-    float key = miss ? __builtin_inff() : first;
+    const uint64_t missM = laneMask(first > second);
+    key = first <= 0.0f ? second : first;
+    enterM = laneMask(!(limit < key)) & ~missM;
     if (MODE != BOX_OUTSIDE) {
-        const bool in = fmaxf(fmaxf(dlx, dly), dlz) <= 0.0f && fminf(fminf(dhx, dhy), dhz) >= 0.0f;
-        key = in ? 0.0f : key;
+        const uint64_t inM = laneMask(fmaxf(fmaxf(dlx, dly), dlz) <= 0.0f) & laneMask(fminf(fminf(dhx, dhy), dhz) >= 0.0f);
+        if (inM & partM) { // (rare below the first levels: most rays start outside most boxes)
+            key = selectByMask(inM, 0.0f, key);
+            enterM |= inM & partM;
+        }
     }
-    return key;
-}
-template <int MODE, bool ANYSIGN>
-RTX_DEV float childKey(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im, float limit)
-{
-    if (MODE == BOX_LITERAL) {
-        float key;
-        const bool h = childTest(mk(lox, loy, loz), mk(hix, hiy, hiz), om, im, limit, key);
-        return h ? key : __builtin_inff();
-    }
-    return childKeyMirrored<MODE, ANYSIGN>(lox, loy, loz, hix, hiy, hiz, om, im);
 }
 
 // `alive`: the lanes of this call (passed the root box; for the mirrored modes: same octant,
@@ -618,32 +616,32 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
             // once a child turns out to be entered: the empty statement keeps the load up here)
             asm volatile("" ::"s"(R.x), "s"(R.y), "s"(R.z), "s"(R.w));
             const float limit = selectByMask(actM, t, -inf); // (a lane that sits this subtree out enters nothing)
-            const float k0 = childKey<MODE, ANYSIGN>(XL.x, YL.x, ZL.x, XH.x, YH.x, ZH.x, om, im, limit);
-            const float k1 = childKey<MODE, ANYSIGN>(XL.y, YL.y, ZL.y, XH.y, YH.y, ZH.y, om, im, limit);
-            float k2 = childKey<MODE, ANYSIGN>(XL.z, YL.z, ZL.z, XH.z, YH.z, ZH.z, om, im, limit);
-            float k3 = childKey<MODE, ANYSIGN>(XL.w, YL.w, ZL.w, XH.w, YH.w, ZH.w, om, im, limit);
+            float k0, k1, k2, k3;
+            uint64_t b0, b1, b2, b3; // the lanes that enter each child
+            childVisit<MODE, ANYSIGN>(XL.x, YL.x, ZL.x, XH.x, YH.x, ZH.x, om, im, limit, actM, k0, b0);
+            childVisit<MODE, ANYSIGN>(XL.y, YL.y, ZL.y, XH.y, YH.y, ZH.y, om, im, limit, actM, k1, b1);
+            childVisit<MODE, ANYSIGN>(XL.z, YL.z, ZL.z, XH.z, YH.z, ZH.z, om, im, limit, actM, k2, b2);
+            childVisit<MODE, ANYSIGN>(XL.w, YL.w, ZL.w, XH.w, YH.w, ZH.w, om, im, limit, actM, k3, b3);
             if (MODE == BOX_LITERAL || ANYSIGN) {
                 // (a test that orders each axis' two planes itself reads the inverted planes of
                 // an unused slot as all of space: go by the child count)
                 const int nChildren = __float_as_int(p[7].x);
-                k2 = nChildren > 2 ? k2 : inf;
-                k3 = nChildren > 3 ? k3 : inf;
+                b2 = nChildren > 2 ? b2 : 0;
+                b3 = nChildren > 3 ? b3 : 0;
             }
             if (COUNT)
                 tc.boxTests += uint32_t((actM >> (threadIdx.x & 63u)) & 1u) * 4u;
-            const bool h0 = !(limit < k0), h1 = !(limit < k1), h2 = !(limit < k2), h3 = !(limit < k3);
-            const uint64_t b0 = laneMask(h0), b1 = laneMask(h1), b2 = laneMask(h2), b3 = laneMask(h3);
             // The children are stored nearest first for this octant: the walk goes on in the
             // first one any lane enters and keeps the others, farthest first, for later.
             const int first = b0 ? 0 : b1 ? 1 : b2 ? 2 : b3 ? 3 : 4;
             if (first < 4) {
                 const int32_t r0 = __float_as_int(R.x), r1 = __float_as_int(R.y), r2 = __float_as_int(R.z), r3 = __float_as_int(R.w);
                 if (b3 && first < 3)
-                    st.pushWave(sp++, r3, h3 ? k3 : inf); // (an infinite key: not this lane's subtree)
+                    st.pushWave(sp++, r3, selectByMask(b3, k3, inf)); // (an infinite key: not this lane's subtree)
                 if (b2 && first < 2)
-                    st.pushWave(sp++, r2, h2 ? k2 : inf);
+                    st.pushWave(sp++, r2, selectByMask(b2, k2, inf));
                 if (b1 && first < 1)
-                    st.pushWave(sp++, r1, h1 ? k1 : inf);
+                    st.pushWave(sp++, r1, selectByMask(b1, k1, inf));
                 cur = first == 0 ? r0 : first == 1 ? r1 : first == 2 ? r2 : r3;
                 actM = first == 0 ? b0 : first == 1 ? b1 : first == 2 ? b2 : b3; // (the lanes that enter it)
                 continue;
