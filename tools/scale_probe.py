@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--workload", default="headline", choices=["headline", "winding", "area_glossy", "big_scene"], help="bench.py's workloads")
     ap.add_argument("--slots", type=int, default=1, help="frames in flight (rtx_select_slot): frame i is queued in slot i %% slots on that slot's stream")
     args = ap.parse_args()
     import torch
@@ -28,9 +29,14 @@ def main():
     from raytracer_amd.scene import dragon_scene, make_camera, make_params
 
     hip = engine.hip_lib()
-    W, H = 1920, 1080
-    f = abi.features(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
-    gpu = engine.GpuEngine(dragon_scene(), f)
+    import bench
+    wargs = argparse.Namespace(workload=args.workload, width=1920, height=1080, spp=16, obj_npz=None)
+    if args.workload == "big_scene":
+        wargs.width, wargs.height = 3840, 2160
+    wl = bench.workload(args.workload, wargs)
+    W, H = wargs.width, wargs.height
+    f = wl["features"]
+    gpu = engine.GpuEngine(wl["scene"], f, device_build=args.workload == "big_scene")
     cam = engine.device_camera(make_camera(), W, H)
     dev = torch.device("cuda", 0)
     streams = engine.concurrent_streams(args.slots, dev)
@@ -44,7 +50,7 @@ def main():
     for world in [int(w) for w in args.worlds.split(",")]:
         worst = 0.0
         for rank in range(world):
-            rp = make_params(W, H, driver=abi.DRIVER_MRAYS, samples=16, tile_size=args.tile, tile_rank=rank, tile_world=world)
+            rp = make_params(W, H, tile_size=args.tile, tile_rank=rank, tile_world=world, **wl["params"])
             per = hip.rtx_tiles_per_rank(C.byref(rp))
             tiles = [torch.zeros((per, args.tile, args.tile, 3), dtype=torch.float32, device=dev) for _ in range(args.slots)]
             n = [0]
@@ -74,7 +80,7 @@ def main():
             dev_ms = e0.elapsed_time(e1) / args.steps
             worst = max(worst, dev_ms)
             print(f"world {world} rank {rank}: device {dev_ms*1e3:7.1f} us/frame, host enqueue {host/args.steps*1e6:6.1f} us/frame", flush=True)
-        rp = make_params(W, H, driver=abi.DRIVER_MRAYS, samples=16, tile_size=args.tile, tile_rank=0, tile_world=world)
+        rp = make_params(W, H, tile_size=args.tile, tile_rank=0, tile_world=world, **wl["params"])
         per = hip.rtx_tiles_per_rank(C.byref(rp))
         allt = torch.zeros((world, per, args.tile, args.tile, 3), dtype=torch.float32, device=dev)
         for _ in range(3):
@@ -87,7 +93,7 @@ def main():
         e1.record(stream)
         torch.cuda.synchronize()
         det = e0.elapsed_time(e1) / args.steps
-        print(f"world {world}: slowest rank {worst*1e3:.1f} us, detile {det*1e3:.1f} us  -> ideal {1371.0/world:.1f} us", flush=True)
+        print(f"world {world}: slowest rank {worst*1e3:.1f} us, detile {det*1e3:.1f} us", flush=True)
     gpu.close()
 
 
