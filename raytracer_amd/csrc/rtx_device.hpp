@@ -50,6 +50,21 @@ struct Ray {
     float t;
 };
 
+// The records of the wave-shared walk re-expressed for rays that all start at ONE point (the
+// camera rays of a pinhole camera; the shadow rays of a point light, which start at the light):
+// `nodes` = the eight octant copies of DScene::waveNodes with every box plane replaced by
+// (plane - origin) in that copy's mirror image, `tris` = DScene::waveTris with each plane's D
+// replaced by D - dot(n, origin).  These are the very subtractions and the very dot product
+// every ray of such a bundle would make at every visit (same operands, same fp32 operations,
+// same order), made once per origin instead: the walk's arithmetic and results are bit for bit
+// the same.  (Whole copies rather than side arrays: the walk then needs no more scalar
+// registers than without a frame.)
+struct OriginFrame {
+    const float4* nodes;
+    const float4* tris;
+};
+constexpr int kLightFrames = 4; // point lights of a scene that get a frame at upload (the first ones)
+
 // --------------------------------------------------------- device scene -----
 struct DScene {
     // Node and triangle records live in ONE array, nodes first: record r of a child
@@ -70,6 +85,7 @@ struct DScene {
     // (v1, -), v2 - v0, v2 - v1, v1 - v0.
     const float4* waveNodes;
     const float4* waveTris;
+    OriginFrame lightFrame[kLightFrames]; // light i's frame if it is a point light (nodes == nullptr: none)
     int32_t nWaveNodes;
     int32_t waveRoot;        // 0 (the root node), ~first triangle when the root is a leaf
     int32_t boxesNested;     // every child box lies within its parent's box, the root's children within the root box
@@ -587,14 +603,18 @@ RTX_DEV void childVisit(float lox, float loy, float loz, float hix, float hiy, f
 // `alive`: the lanes of this call (passed the root box; for the mirrored modes: same octant,
 // finite 1/d).  t and bestK as in traverseBvh; with EARLY a lane stops taking part once it
 // knows a hit below tStop.
-template <int STACK, bool COUNT, bool EARLY, int MODE, bool ANYSIGN = false>
-RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, V3 inv, bool alive, uint32_t oct, float& t, int& bestK, TraceCounters& tc, float tStop)
+// REL: all rays of the call start at the origin `fr` was made for; its records are read instead
+// (not for the literal test, nor for bundles that straddle octants).
+template <int STACK, bool COUNT, bool EARLY, int MODE, bool ANYSIGN = false, bool REL = false>
+RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d, V3 inv, bool alive, uint32_t oct, float& t, int& bestK, TraceCounters& tc, float tStop, OriginFrame fr = OriginFrame { nullptr, nullptr })
 {
+    static_assert(!REL || (MODE != BOX_LITERAL && !ANYSIGN), "origin frames serve the mirrored box tests of one octant");
     const bool nx = MODE != BOX_LITERAL && (oct & 1u) != 0, ny = MODE != BOX_LITERAL && (oct & 2u) != 0, nz = MODE != BOX_LITERAL && (oct & 4u) != 0; // wave-uniform
-    const V3 om = mk(nx ? -o.x : o.x, ny ? -o.y : o.y, nz ? -o.z : o.z);
+    // (with a frame the planes come with the origin already subtracted: x - 0 is x)
+    const V3 om = REL ? mk(0.0f, 0.0f, 0.0f) : mk(nx ? -o.x : o.x, ny ? -o.y : o.y, nz ? -o.z : o.z);
     const V3 im = MODE == BOX_LITERAL ? inv : ANYSIGN ? mk(nx ? -inv.x : inv.x, ny ? -inv.y : inv.y, nz ? -inv.z : inv.z) : mk(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z));
-    const UniformF4* const nodes = uniformRecords(sc.waveNodes) + size_t(MODE == BOX_LITERAL ? 0u : oct) * size_t(uint32_t(sc.nWaveNodes)) * kWaveNodeQuads;
-    const UniformF4* const tris = uniformRecords(sc.waveTris);
+    const UniformF4* const nodes = uniformRecords(REL ? fr.nodes : sc.waveNodes) + size_t(MODE == BOX_LITERAL ? 0u : oct) * size_t(uint32_t(sc.nWaveNodes)) * kWaveNodeQuads;
+    const UniformF4* const tris = uniformRecords(REL ? fr.tris : sc.waveTris);
     const float inf = __builtin_inff();
     int sp = 0;
     int32_t cur = __builtin_amdgcn_readfirstlane(sc.waveRoot);
@@ -659,8 +679,12 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                 // the plane part of triangleTest.  (Its `dn == 0` rejection needs no test of its own:
                 // the quotient is then an infinity or a NaN, which fails one of the two comparisons.)
                 const float dn = P.x * d.x + P.y * d.y + P.z * d.z;
-                const float no = P.x * o.x + P.y * o.y + P.z * o.z;
-                const float th = (P.w - no) / dn;
+                float num = P.w; // (with a frame: D - dot(n, origin) already)
+                if (!REL) {
+                    const float no = P.x * o.x + P.y * o.y + P.z * o.z;
+                    num = P.w - no;
+                }
+                const float th = num / dn;
                 const bool behind = th <= 0.f, nearer = th < t;
                 const uint64_t okM = actM & ~laneMask(behind) & laneMask(nearer);
                 if (okM) {
@@ -720,8 +744,9 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
 // pass per direction octant present among them, and one for the rays whose reciprocal
 // direction is not finite (axis-parallel rays).  t, bestK, tStop, rootLimit as in
 // traverseBvh.  Must be called by all lanes of the wave together.
-template <int STACK, bool COUNT, bool EARLY, bool SPREAD = false>
-RTX_DEV void traverseWaveTogether(const DScene& sc, LaneStack<STACK>& st, bool lane, V3 o, V3 d, float& t, int& bestK, TraceCounters& tc, float tStop = 0.f, float rootLimit = 0.f)
+template <int STACK, bool COUNT, bool EARLY, bool SPREAD = false, bool REL = false>
+RTX_DEV void traverseWaveTogether(const DScene& sc, LaneStack<STACK>& st, bool lane, V3 o, V3 d, float& t, int& bestK, TraceCounters& tc, float tStop = 0.f, float rootLimit = 0.f,
+    OriginFrame fr = OriginFrame { nullptr, nullptr })
 {
     bestK = -1;
     if (sc.rootRef == kEmptyRoot)
@@ -759,10 +784,11 @@ RTX_DEV void traverseWaveTogether(const DScene& sc, LaneStack<STACK>& st, bool l
     while (rest) {
         const uint32_t oct = uint32_t(__builtin_amdgcn_readlane(int(myOct), __builtin_ctzll(rest)));
         const bool mine = in && finiteInv && myOct == oct;
+        // (REL: the caller knows that all its rays start at the frame's origin)
         if (!anyLane(mine && !outside))
-            traverseBvhWave<STACK, COUNT, EARLY, BOX_OUTSIDE>(sc, st, o, d, inv, mine, oct, t, bestK, tc, tStop);
+            traverseBvhWave<STACK, COUNT, EARLY, BOX_OUTSIDE, false, REL>(sc, st, o, d, inv, mine, oct, t, bestK, tc, tStop, fr);
         else
-            traverseBvhWave<STACK, COUNT, EARLY, BOX_MIRRORED>(sc, st, o, d, inv, mine, oct, t, bestK, tc, tStop);
+            traverseBvhWave<STACK, COUNT, EARLY, BOX_MIRRORED, false, REL>(sc, st, o, d, inv, mine, oct, t, bestK, tc, tStop, fr);
         rest &= ~laneMask(mine);
     }
     if (anyLane(in && !finiteInv))
@@ -916,8 +942,9 @@ RTX_DEV bool intersectScene(const DScene& sc, LaneStack<STACK>& st, const rtx_fe
 
 // closestHit / lightVisibility / intersectScene for a whole wave at once (`lane`: this lane
 // has a query), with the triangles found by the wave-shared walk.  Same results per lane.
-template <int STACK, bool COUNT, bool EARLY = false, bool SPREAD = false>
-RTX_DEV bool closestHitWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 o, V3 d, float& t, int& bestK, int& sphere, V3& sphereN, TraceCounters& tc, float tStop = 0.f, float clip = 0.f)
+template <int STACK, bool COUNT, bool EARLY = false, bool SPREAD = false, bool REL = false>
+RTX_DEV bool closestHitWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 o, V3 d, float& t, int& bestK, int& sphere, V3& sphereN, TraceCounters& tc, float tStop = 0.f, float clip = 0.f,
+    OriginFrame fr = OriginFrame { nullptr, nullptr })
 {
     sphere = -1;
     sphereN = mk(0, 0, 0);
@@ -934,13 +961,13 @@ RTX_DEV bool closestHitWave(const DScene& sc, LaneStack<STACK>& st, const rtx_fe
     if (EARLY)
         t = (clip < t) ? clip : t;
     if (f.enable_accel_structure)
-        traverseWaveTogether<STACK, COUNT, EARLY, SPREAD>(sc, st, lane, o, d, t, bestK, tc, tStop, afterSpheres);
+        traverseWaveTogether<STACK, COUNT, EARLY, SPREAD, REL && !SPREAD>(sc, st, lane, o, d, t, bestK, tc, tStop, afterSpheres, fr);
     else if (lane)
         traverseAll<COUNT>(sc, o, d, t, bestK, tc);
     return lane && (bestK >= 0 || sphere >= 0);
 }
-template <int STACK, bool COUNT, bool SPREAD = false>
-RTX_DEV float lightVisibilityWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 pos, V3 hp, TraceCounters& tc)
+template <int STACK, bool COUNT, bool SPREAD = false, bool REL = false>
+RTX_DEV float lightVisibilityWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 pos, V3 hp, TraceCounters& tc, OriginFrame fr = OriginFrame { nullptr, nullptr })
 {
     const V3 sd = hp - pos;
     const float len = length(sd);
@@ -952,16 +979,16 @@ RTX_DEV float lightVisibilityWave(const DScene& sc, LaneStack<STACK>& st, const 
     }
     int bk, sph;
     V3 sn;
-    closestHitWave<STACK, COUNT, true, SPREAD>(sc, st, f, lane, pos, sd, ts, bk, sph, sn, tc, tStop, clip);
+    closestHitWave<STACK, COUNT, true, SPREAD, REL>(sc, st, f, lane, pos, sd, ts, bk, sph, sn, tc, tStop, clip, fr);
     const V3 second = pos + ts * sd;
     return (double(distance(hp, second)) > 1e-3) ? 0.0f : 1.0f;
 }
-template <int STACK, bool COUNT>
-RTX_DEV bool intersectSceneWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 o, V3 d, float& t, Hit& hit, TraceCounters& tc)
+template <int STACK, bool COUNT, bool REL = false>
+RTX_DEV bool intersectSceneWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool lane, V3 o, V3 d, float& t, Hit& hit, TraceCounters& tc, OriginFrame fr = OriginFrame { nullptr, nullptr })
 {
     int bestK, sphere;
     V3 sphereN;
-    const bool any = closestHitWave<STACK, COUNT>(sc, st, f, lane, o, d, t, bestK, sphere, sphereN, tc);
+    const bool any = closestHitWave<STACK, COUNT, false, false, REL>(sc, st, f, lane, o, d, t, bestK, sphere, sphereN, tc, 0.f, 0.f, fr);
     hitAttributes(sc, f, o, d, t, bestK, sphere, sphereN, hit);
     return any;
 }

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -324,6 +325,7 @@ struct RenderArgs {
     DScene sc;
     rtx_features f;
     rtx_camera cam, prev;
+    OriginFrame camFrame; // the scene's records relative to cam.position (nodes == nullptr: none); only for drivers whose camera rays all start there
     int32_t W, H, driver, depth, samples, shadowSamples, glossyRays;
     uint32_t seed;
     float aperture, focal;
@@ -1087,7 +1089,9 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
 // pixels from one camera position); otherwise lane by lane (the depth-of-field driver, whose
 // samples start all over the lens and cross at the focal point: walked together such a wave
 // visits the union of its lanes' nodes, 32 ms instead of 10 ms on the 10 M-triangle scene).
-template <int STACK, bool COUNT, bool TOGETHER = true>
+// REL: the camera rays all start at the camera position and every light that counts is a point
+// light, and the frames of those origins are at hand (A.camFrame, sc.lightFrame).
+template <int STACK, bool COUNT, bool TOGETHER = true, bool REL = false>
 RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, bool active, LaneCounters& lc)
 {
     const DScene& sc = A.sc;
@@ -1099,7 +1103,7 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
     lc.countPrimary(active);
     lc.countTraced(active);
     if (TOGETHER)
-        any = intersectSceneWave<STACK, COUNT>(sc, st, f, active, o, d, t, hit, lc.tc);
+        any = intersectSceneWave<STACK, COUNT, REL>(sc, st, f, active, o, d, t, hit, lc.tc, A.camFrame);
     else if (active)
         any = intersectScene<STACK, COUNT>(sc, st, f, o, d, t, hit, lc.tc);
     const bool shade = any && f.enable_shading;
@@ -1135,8 +1139,9 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
             const bool facing = shade && lightFacesSurface(pos, hp, visN);
             lc.countTraced(facing);
             float visible = 0.0f;
-            if (TOGETHER)
-                visible = lightVisibilityWave<STACK, COUNT>(sc, st, f, facing, pos, hp, lc.tc);
+            if (TOGETHER) // (the shadow rays start at the light: its frame, if it has one)
+                visible = lightVisibilityWave<STACK, COUNT, false, REL>(sc, st, f, facing, pos, hp, lc.tc,
+                    li == 0 ? sc.lightFrame[0] : li == 1 ? sc.lightFrame[1] : li == 2 ? sc.lightFrame[2] : sc.lightFrame[3]);
             else if (facing)
                 visible = lightVisibility<STACK, COUNT>(sc, st, f, pos, hp, visN, lc.tc);
             if (shade)
@@ -1539,7 +1544,7 @@ template <int STACK, bool COUNT, int MODE>
 __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A)
 {
     constexpr bool FULL = MODE >= 1 && MODE <= 4;
-    constexpr bool BLUR = FULL || MODE >= 6; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
+    constexpr bool BLUR = FULL || MODE == 6 || MODE == 7; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
     __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
     extern __shared__ int32_t sFan[]; // MODE 4: fanLevels * fan size * kBlock distances, then as many triangle records
@@ -1688,7 +1693,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
                 walkPath<STACK, COUNT>(A, st, fan, o, d, active, key, storeIndex * uint32_t(A.samples) + uint32_t(sample), lc);
                 continue; // (the pixel is written by resolveKernel)
             }
-            const V3 c = MODE == 4 ? mk(0, 0, 0) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6>(A, st, o, d, active, lc);
+            const V3 c = MODE == 4 ? mk(0, 0, 0) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6 || MODE == 8, MODE == 8>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
             } else if (!anyLane(!(c.x == 0.f && c.y == 0.f && c.z == 0.f))) {
@@ -2195,6 +2200,38 @@ __global__ void __launch_bounds__(kBlock, RTX_FULL_WAVES) shadeKernel(ShadeArgs 
 }
 
 // scatter gathered compact tile buffers into a Screen-layout frame
+// Makes an OriginFrame: thread i < 8 * nWide rewrites four-wide node i of the eight octant
+// copies (every plane minus the origin's coordinate in that copy's mirror image; references
+// and child count copied), thread j < nTris + 1 copies triangle record j (the padding record
+// included) with D - dot(n, origin) in place of D -- the operations traverseBvhWave makes per
+// ray without a frame.
+__global__ void __launch_bounds__(256) originFrameKernel(const float4* waveNodes, uint32_t nWide, const float4* waveTris, uint32_t nTris, float ox, float oy, float oz, float4* relNodes, float4* relTris)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 8u * nWide) {
+        const uint32_t oct = i / nWide;
+        const float mx = (oct & 1u) ? -ox : ox, my = (oct & 2u) ? -oy : oy, mz = (oct & 4u) ? -oz : oz;
+        const float4* src = waveNodes + size_t(i) * 8;
+        float4* dst = relNodes + size_t(i) * 8;
+        for (int q = 0; q < 6; q++) {
+            const float m = q < 2 ? mx : q < 4 ? my : mz;
+            const float4 v = src[q];
+            dst[q] = make_float4(v.x - m, v.y - m, v.z - m, v.w - m);
+        }
+        dst[6] = src[6];
+        dst[7] = src[7];
+    }
+    if (i <= nTris) {
+        const float4* src = waveTris + size_t(i) * 6;
+        float4* dst = relTris + size_t(i) * 6;
+        const float4 P = src[0];
+        const float no = P.x * ox + P.y * oy + P.z * oz;
+        dst[0] = make_float4(P.x, P.y, P.z, P.w - no);
+        for (int q = 1; q < 6; q++)
+            dst[q] = src[q];
+    }
+}
+
 __global__ void detileKernel(const float* tiles, float* out, int W, int H, int ts, int tilesX, int tilesY, int world, int tilesPerRank)
 {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -2279,6 +2316,14 @@ struct DeviceCtx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evSwitch = nullptr;            // orders the old stream's work before the new stream's (rtx_set_stream)
     int numCUs = 0;
+    // the OriginFrame of the camera position last rendered from (see ensureCameraFrame)
+    struct CameraFrame {
+        float4 *nodes = nullptr, *tris = nullptr;
+        size_t nodeBytes = 0, triBytes = 0;
+        bool valid = false, haveLast = false;
+        uint64_t sceneId = 0, lastSceneId = 0;
+        float pos[3] = {}, lastPos[3] = {};
+    } cameraFrame;
     std::mutex launch;                        // one frame / batch at a time per GPU
     Arena heap;                               // allocated in rtx_init
     Arena fixed;                              // views into this GPU's copy of `scratch`
@@ -2332,8 +2377,10 @@ struct rtx_scene {
     int device = -1;
     int refs = 1;
     DScene d {};
-    void* buffers[16] = {};
+    void* buffers[32] = {};
     int nBuffers = 0;
+    uint64_t id = 0;           // never reused (a slot's camera frame remembers which scene it was made for)
+    std::vector<std::array<float, 3>> lightPos; // p[0] of every light
     int numLevels = 0;
     bool hasEnv = false;
     bool hasAreaLight = false; // a segment or parallelogram light
@@ -2360,6 +2407,84 @@ int upload(rtx_scene* s, const T* src, size_t count, const T** dst)
     if (count)
         HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
     *dst = static_cast<const T*>(p);
+    return RTX_OK;
+}
+
+std::atomic<uint64_t> g_sceneIds { 0 };
+bool originFramesOff() { return getenv("RTX_NO_ORIGIN_FRAMES") != nullptr; } // diagnostic
+
+size_t frameNodeBytes(const rtx_scene* s) { return std::max<size_t>(size_t(uint32_t(s->d.nWaveNodes)) * 8, 1) * 8 * sizeof(float4); }
+size_t frameTriBytes(const rtx_scene* s) { return (size_t(uint32_t(s->d.nTris)) + 1) * 6 * sizeof(float4); }
+void launchOriginFrame(const rtx_scene* s, const float* pos, float4* nodes, float4* tris, hipStream_t stream)
+{
+    const uint32_t nWide = uint32_t(s->d.nWaveNodes), nTris = uint32_t(s->d.nTris);
+    const uint64_t threads = std::max<uint64_t>(8ull * nWide, uint64_t(nTris) + 1);
+    hipLaunchKernelGGL(originFrameKernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, stream, s->d.waveNodes, nWide, s->d.waveTris, nTris, pos[0], pos[1], pos[2], nodes, tris);
+}
+
+// The frames of the scene's first point lights (their shadow rays all start at the light),
+// made once at upload.  The scene's wave records must be in place.
+int makeLightFrames(rtx_scene* s, hipStream_t stream)
+{
+    s->id = ++g_sceneIds;
+    for (int i = 0; i < kLightFrames; i++)
+        s->d.lightFrame[i] = OriginFrame { nullptr, nullptr };
+    if (s->d.nTris <= 0 || !s->d.waveTris)
+        return RTX_OK;
+    for (size_t li = 0; li < s->lightTypes.size() && li < size_t(kLightFrames); li++) {
+        if (s->lightTypes[li] != RTX_LIGHT_POINT)
+            continue;
+        void *nodes = nullptr, *num = nullptr; // (the node copies, the triangle copy)
+        HIP_TRY(hipMalloc(&nodes, frameNodeBytes(s)));
+        s->buffers[s->nBuffers++] = nodes;
+        HIP_TRY(hipMalloc(&num, frameTriBytes(s)));
+        s->buffers[s->nBuffers++] = num;
+        launchOriginFrame(s, s->lightPos[li].data(), static_cast<float4*>(nodes), static_cast<float4*>(num), stream);
+        HIP_TRY(hipGetLastError());
+        s->d.lightFrame[li] = OriginFrame { static_cast<const float4*>(nodes), static_cast<const float4*>(num) };
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return RTX_OK;
+}
+
+// The frame of the camera position for drivers whose camera rays all start there, kept per
+// frame slot and remade (one small kernel on the slot's stream) when the scene or the position
+// changes.  A scene whose copy is large (> 256 MB) gets one only from the second frame in a
+// row from the same position: for a moving camera the copy would cost what it saves.
+int ensureCameraFrame(DeviceCtx* c, const rtx_scene* s, const float* pos, OriginFrame& out)
+{
+    out = OriginFrame { nullptr, nullptr };
+    DeviceCtx::CameraFrame& F = c->cameraFrame;
+    if (F.valid && F.sceneId == s->id && std::memcmp(F.pos, pos, sizeof(F.pos)) == 0) {
+        out = OriginFrame { F.nodes, F.tris };
+        return RTX_OK;
+    }
+    const size_t nodeBytes = frameNodeBytes(s), triBytes = frameTriBytes(s);
+    const bool repeated = F.haveLast && F.lastSceneId == s->id && std::memcmp(F.lastPos, pos, sizeof(F.lastPos)) == 0;
+    F.haveLast = true;
+    F.lastSceneId = s->id;
+    std::memcpy(F.lastPos, pos, sizeof(F.lastPos));
+    if (nodeBytes + triBytes > (size_t(256) << 20) && !repeated)
+        return RTX_OK;
+    F.valid = false;
+    if (nodeBytes > F.nodeBytes || triBytes > F.triBytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream)); // nothing queued may still read what is freed below
+        if (F.nodes)
+            (void)hipFree(F.nodes);
+        if (F.tris)
+            (void)hipFree(F.tris);
+        F.nodes = F.tris = nullptr, F.nodeBytes = F.triBytes = 0;
+        HIP_TRY(hipMalloc((void**)&F.nodes, nodeBytes));
+        F.nodeBytes = nodeBytes;
+        HIP_TRY(hipMalloc((void**)&F.tris, triBytes));
+        F.triBytes = triBytes;
+    }
+    launchOriginFrame(s, pos, F.nodes, F.tris, c->stream);
+    HIP_TRY(hipGetLastError());
+    F.valid = true;
+    F.sceneId = s->id;
+    std::memcpy(F.pos, pos, sizeof(F.pos));
+    out = OriginFrame { F.nodes, F.tris };
     return RTX_OK;
 }
 
@@ -2440,6 +2565,7 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode, size_t
     }
 #define RTX_LAUNCH_MODES(CNT)                                                                                     \
     switch (mode) {                                                                                               \
+    case 8: RTX_LAUNCH(CNT, 8) break;                                                                             \
     case 7: RTX_LAUNCH(CNT, 7) break;                                                                             \
     case 6: RTX_LAUNCH(CNT, 6) break;                                                                             \
     case 5: RTX_LAUNCH(CNT, 5) break;                                                                             \
@@ -2920,6 +3046,23 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : driver != RTX_DRIVER_DOF && A.lanesPerPixel >= 2;
     // (the motion-blur driver's lean kernels carry the per-sample camera's trigonometry: modes 6 / 7)
     const int mode = !full ? (driver == RTX_DRIVER_MOTION_BLUR ? (together ? 6 : 7) : (together ? 0 : 5)) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
+    // Mode 8 = mode 0 with every ray of the frame read from an origin's frame: the camera rays
+    // of these drivers all start at the camera position, the shadow rays at their point light.
+    // (The fixed-workspace entry point must not allocate and goes without: same arithmetic,
+    // same pixels.)
+    A.camFrame = OriginFrame { nullptr, nullptr };
+    int launchMode = mode;
+    if (mode == 0 && !fixedArena && !originFramesOff() && (driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS) && f->enable_accel_structure && scene->d.nTris > 0) {
+        bool lightsHaveFrames = scene->lightTypes.size() <= size_t(kLightFrames);
+        for (size_t li = 0; li < scene->lightTypes.size() && lightsHaveFrames; li++) // (other kinds do not count in the lean kernels)
+            lightsHaveFrames = scene->lightTypes[li] != RTX_LIGHT_POINT || scene->d.lightFrame[li].nodes != nullptr;
+        if (lightsHaveFrames) {
+            if (int rc = ensureCameraFrame(c, scene, cam->position, A.camFrame))
+                return rc;
+            if (A.camFrame.nodes)
+                launchMode = 8;
+        }
+    }
     A.runIf = nullptr;
     A.defer = Deferred {};
     size_t walkLds = 0;
@@ -3183,7 +3326,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     if (stats) // (an event record costs the stream a few microseconds around the kernel: only when the time is asked for)
         HIP_TRY(hipEventRecord(c->ev0, c->stream)); // kernel_ms is the render kernel's time
     if (A.work.nUnits) {
-        launch(A, mode, 0);
+        launch(A, launchMode, 0);
         HIP_TRY(hipGetLastError());
     }
     if (stats)
@@ -3336,6 +3479,7 @@ int uploadShading(rtx_scene* s, const rtx_scene_desc* d)
     for (uint32_t i = 0; i < d->n_lights; i++) {
         s->hasAreaLight = s->hasAreaLight || d->lights[i].type != RTX_LIGHT_POINT;
         s->lightTypes.push_back(d->lights[i].type);
+        s->lightPos.push_back({ d->lights[i].p[0][0], d->lights[i].p[0][1], d->lights[i].p[0][2] });
     }
     s->d.nSpheres = int32_t(d->n_spheres);
     s->d.nMaterials = int32_t(d->n_materials);
@@ -3835,6 +3979,10 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     s->d.rootRef = (d->root_ref < 0 && d->root_ref != kEmptyRoot) ? ~int32_t(d->n_nodes + uint32_t(~d->root_ref)) : d->root_ref;
     memcpy(s->d.rootLo, d->root_lo, sizeof(s->d.rootLo));
     memcpy(s->d.rootHi, d->root_hi, sizeof(s->d.rootHi));
+    if (makeLightFrames(s, g_ctx->stream)) {
+        rtx_scene_destroy(s);
+        return nullptr;
+    }
     return s;
 }
 
@@ -4082,6 +4230,10 @@ rtx_scene* rtx_scene_build_device(const rtx_scene_desc* d)
     s->d.rootRef = 0;
     std::memcpy(s->d.rootLo, rootBox, 12);
     std::memcpy(s->d.rootHi, rootBox + 3, 12);
+    if (makeLightFrames(s, g_ctx->stream)) {
+        rtx_scene_destroy(s);
+        return nullptr;
+    }
     return s;
 }
 

@@ -344,6 +344,42 @@ def test_frames_in_flight_in_several_slots_equal_the_frames_rendered_alone(gpu_d
         area.close()
 
 
+def test_origin_frames_do_not_change_frames(gpu_device, monkeypatch):
+    """Jittered frames under point lights read the scene through records made relative to the
+    rays' common origins (the camera position, remade when the camera moves; each point light's
+    position, made at upload).  The frames must be, bit for bit and ray for ray, those of the
+    plain records (RTX_NO_ORIGIN_FRAMES): a camera that moves between frames and comes back, two
+    point lights beside a segment light that does not count, host-built and device-built tree,
+    and a scene with more point lights than get a frame."""
+    scenes = []
+    two = dragon_scene(subdivisions=4)
+    two.lights = [abi.point_light((-1, 1, -1), (1, 1, 1)), abi.segment_light((0.3, 0.9, -0.2), (-0.3, 0.9, 0.2), (0.9, 0.2, 0.1), (0.2, 1, 0.3)),
+                  abi.point_light((1.5, 0.5, 0.8), (0.3, 0.5, 0.9))]
+    scenes.append(("two point lights", two, False))
+    scenes.append(("two point lights, device-built tree", two, True))
+    many = dragon_scene(subdivisions=3)
+    many.lights = [abi.point_light((np.cos(a), 1.0, np.sin(a)), (0.2, 0.2, 0.2)) for a in np.linspace(0, 5, 6)]
+    scenes.append(("six point lights", many, False))
+    cams = [make_camera(), make_camera(distance=1.4, rotation_degrees=(35, -50, 0)), make_camera(look_at=(0.2, 0.1, 0.0)), make_camera()]
+    f = abi.features(**cases.BASE)
+    rp = make_params(200, 120, driver=abi.DRIVER_MRAYS, samples=8)
+    for name, scene, device_build in scenes:
+        gpu = GpuEngine(scene, f, device_build=device_build)
+        got = []
+        for cam in cams:
+            got.append((gpu.render(cam, f, rp), (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.shaded_hits, gpu.stats.rays_traced)))
+        monkeypatch.setenv("RTX_NO_ORIGIN_FRAMES", "1")
+        for i, cam in enumerate(cams):
+            plain = gpu.render(cam, f, rp)
+            counts = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.shaded_hits, gpu.stats.rays_traced)
+            assert np.array_equal(_bits(got[i][0]), _bits(plain)), f"{name}: frame {i} differs from the frame on the plain records"
+            assert got[i][1] == counts, f"{name}: frame {i} counts {got[i][1]} vs {counts}"
+        monkeypatch.delenv("RTX_NO_ORIGIN_FRAMES")
+        assert np.array_equal(_bits(got[0][0]), _bits(got[3][0])) and got[0][1][1] > 0 and np.nanmax(got[0][0]) > 0
+        assert not np.array_equal(_bits(got[0][0]), _bits(got[1][0]))
+        gpu.close()
+
+
 def test_shadow_query_shortcuts_do_not_change_frames(gpu_device):
     """The shortened shadow queries must give the reference's answer in the regimes
     where they switch on and off: light closer than 0.2 to surfaces, coordinates
