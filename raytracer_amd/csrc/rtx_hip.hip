@@ -3041,9 +3041,12 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // lights: with a full wave of paths the lanes' own traversals already run side by side)
     const bool fans = f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1 && A.glossyRays <= kFanMax
         && A.pixelsPerUnit * A.lanesPerPixel <= 8 && !getenv("RTX_NO_FANS");
-    // (the lens samples of the depth-of-field driver make no coherent bundle, and 64 pixels with one
-    // sample each share too little of the tree below its top levels: lane by lane; RTX_LEAN_WALK=0/1 overrides)
-    const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : driver != RTX_DRIVER_DOF && A.lanesPerPixel >= 2;
+    // (the lens samples of the depth-of-field driver make no coherent bundle; 64 neighbouring pixels
+    // with one sample each share enough of the tree only while triangles are large on the screen --
+    // measured at 3840x2160: together wins up to ~0.3 triangles per pixel, 0.60 against 0.87 ms at
+    // 0.04, and loses beyond, 1.41 against 1.26 ms at 1.2; RTX_LEAN_WALK=0/1 overrides)
+    const bool sparse = double(scene->d.nTris) <= 0.3 * double(A.W) * double(A.H);
+    const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : driver != RTX_DRIVER_DOF && (A.lanesPerPixel >= 2 || sparse);
     // (the motion-blur driver's lean kernels carry the per-sample camera's trigonometry: modes 6 / 7)
     const int mode = !full ? (driver == RTX_DRIVER_MOTION_BLUR ? (together ? 6 : 7) : (together ? 0 : 5)) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
     // Mode 8 = mode 0 with every ray of the frame read from an origin's frame: the camera rays
