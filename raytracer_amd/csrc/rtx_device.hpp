@@ -533,12 +533,15 @@ RTX_DEV uint64_t laneMask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 RTX_DEV bool anyLane(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; }
 // m's bit for this lane ? a : b, for a wave mask that scalar instructions made (the result of a
 // vote combined with others: the compiler has no per-lane form of it, and rebuilding one costs
-// more than this select).  The mask must not be the untouched result of a vector compare: the
-// select would read it before the hardware's wait states for such a pair have passed.
+// more than this select).  gfx950 wants two wait states between a vector instruction that
+// writes a scalar register and a vector instruction that reads it; the compiler keeps them for
+// its own code but does not look inside an asm statement, so the statement brings its own (the
+// masks here are written by scalar instructions as the code stands, which need none: the two
+// idle cycles buy independence from how the compiler allocates them).
 RTX_DEV float selectByMask(uint64_t m, float a, float b)
 {
     float r;
-    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    asm("s_nop 1\n\tv_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
     return r;
 }
 RTX_DEV int selectByMask(uint64_t m, int a, int b) { return __float_as_int(selectByMask(m, __int_as_float(a), __int_as_float(b))); }

@@ -2977,6 +2977,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // the odd pixel (8 pixels, 56 of 64 lanes).
     while (64 % A.pixelsPerUnit != 0)
         A.pixelsPerUnit--;
+    const int mostPixelsPerUnit = A.pixelsPerUnit;
     // With area lights every shading point costs the wave a traversal step per 64
     // light samples however few camera samples it carries, so a unit holds few
     // pixels: short units balance better and their camera rays are the small part.
@@ -3020,7 +3021,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     }
     if (const char* e = getenv("RTX_PIXELS_PER_UNIT")) { // diagnostic: 1, 2, 4, ... 64
         const int v = atoi(e);
-        if (v >= 1 && v <= A.pixelsPerUnit && 64 % v == 0)
+        if (v >= 1 && v <= mostPixelsPerUnit && 64 % v == 0)
             A.pixelsPerUnit = v;
     }
     A.rounds = (A.samples + 63) / 64;
