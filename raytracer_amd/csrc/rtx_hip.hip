@@ -317,6 +317,7 @@ struct Deferred {
     uint32_t fanLevels;    // > 0: glossy fans are traced side by side, their hits kept in LDS for this many levels
     uint32_t leafFans;     // the rays of a fan that ends the recursion are finished by the lanes that traced them
     uint32_t fansTogether; // the rays of a fan walk the tree together (closestHitWave): pays when a wave serves one or two fans at a time
+    uint2* primary;        // per (output pixel, sample): the camera ray's closest hit (t bits, triangle record or -1) from the camera pass; nullptr: the walk traces it
 };
 __host__ __device__ inline uint32_t* deferOverflow(const Deferred& D) { return D.counters + 2 * kPools * kPoolStride; }
 
@@ -1228,6 +1229,12 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
     bool preTraced = false;
     float preT = kFltMax;
     int32_t preK = -1;
+    if (D.primary && active) { // the camera pass has traced this sample's camera ray already
+        const uint2 seen = D.primary[headIndex];
+        preTraced = true;
+        preT = __uint_as_float(seen.x);
+        preK = int32_t(seen.y);
+    }
     const int fanGroup = min(max(A.glossyRays, 1), kFanMax), fanPerRound = 64 / fanGroup;
     const int fanSlot = lane / fanGroup, fanChild = lane - fanSlot * fanGroup;
     TapeWriter tape;
@@ -1543,8 +1550,8 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
 template <int STACK, bool COUNT, int MODE>
 __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A)
 {
-    constexpr bool FULL = MODE >= 1 && MODE <= 4;
-    constexpr bool BLUR = FULL || MODE == 6 || MODE == 7; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
+    constexpr bool FULL = MODE >= 1 && MODE <= 4; // (mode 9, the camera pass, needs none of either kind's machinery beyond ray generation)
+    constexpr bool BLUR = FULL || MODE == 6 || MODE == 7 || MODE == 9; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
     __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
     extern __shared__ int32_t sFan[]; // MODE 4: fanLevels * fan size * kBlock distances, then as many triangle records
@@ -1563,6 +1570,8 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
     // bounds, so the rays are counted, the pixels are black (src/render.cpp:61-64) and
     // nothing is traced.  One wave-wide store, lane = pixel.
     auto blackBlock = [&](const BlockPlace& b) {
+        if (MODE == 9)
+            return; // (the camera pass leaves counting and pixels to the walk)
         const uint32_t mx = uint32_t(lane) & 7u, my = uint32_t(lane) >> 3;
         const bool ok = b.listed && int(b.x0 + mx) < A.W && int(b.y0 + my) < A.H;
         lc.primary += uint32_t(__popcll(__ballot(ok))) * uint32_t(A.samples);
@@ -1610,6 +1619,8 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
         if (place.culled) {
             // every camera ray of the unit misses the scene's bounds: the rays are
             // counted, the pixels are black (src/render.cpp:61-64), nothing is traced
+            if (MODE == 9)
+                continue;
             for (int round = 0; round < A.rounds; round++)
                 lc.countPrimary(place.ok && round * A.lanesPerPixel + sub < A.samples);
             if (writer && place.ok) {
@@ -1687,13 +1698,27 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
                     }
                 }
             }
+            if (MODE == 9) {
+                // The camera pass of a deferred frame whose walk holds few pixels per wave: the
+                // camera rays of a full wave of pixels, by the very query the walk would make
+                // for each (closestHit, ray by ray), their hits left for the walk to pick up.
+                float t = kFltMax;
+                int bestK = -1, sphere = -1;
+                V3 sphereN = mk(0, 0, 0);
+                lc.countTraced(active);
+                if (active) {
+                    closestHit<STACK, COUNT>(A.sc, st, A.f, o, d, t, bestK, sphere, sphereN, lc.tc);
+                    A.defer.primary[storeIndex * uint32_t(A.samples) + uint32_t(sample)] = make_uint2(__float_as_uint(t), uint32_t(bestK));
+                }
+                continue;
+            }
             if (MODE == 4) {
                 const int fanRays = min(max(A.glossyRays, 1), kFanMax);
                 const FanStore fan { reinterpret_cast<float*>(sFan), sFan + A.defer.fanLevels * fanRays * kBlock, int(threadIdx.x), fanRays };
                 walkPath<STACK, COUNT>(A, st, fan, o, d, active, key, storeIndex * uint32_t(A.samples) + uint32_t(sample), lc);
                 continue; // (the pixel is written by resolveKernel)
             }
-            const V3 c = MODE == 4 ? mk(0, 0, 0) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6 || MODE == 8, MODE == 8>(A, st, o, d, active, lc);
+            const V3 c = (MODE == 4 || MODE == 9) ? mk(0, 0, 0) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6 || MODE == 8, MODE == 8>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
             } else if (!anyLane(!(c.x == 0.f && c.y == 0.f && c.z == 0.f))) {
@@ -1737,7 +1762,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
                 }
             }
         }
-        if (MODE != 4 && writer && storeIndex != 0xffffffffu) {
+        if (MODE != 4 && MODE != 9 && writer && storeIndex != 0xffffffffu) {
             {
                 const uint32_t outIndex = storeIndex;
                 V3 px = accum;
@@ -2565,6 +2590,7 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode, size_t
     }
 #define RTX_LAUNCH_MODES(CNT)                                                                                     \
     switch (mode) {                                                                                               \
+    case 9: RTX_LAUNCH(CNT, 9) break;                                                                             \
     case 8: RTX_LAUNCH(CNT, 8) break;                                                                             \
     case 7: RTX_LAUNCH(CNT, 7) break;                                                                             \
     case 6: RTX_LAUNCH(CNT, 6) break;                                                                             \
@@ -2870,7 +2896,8 @@ int ensureDeferPools(DeviceCtx* c, size_t headWords, uint32_t nCounting)
             (void)hipFree(P.heads);
         P.heads = nullptr;
         P.headWords = 0;
-        HIP_TRY(hipMalloc((void**)&P.heads, headWords * sizeof(uint32_t)));
+        // (the camera pass's hits, two words per sample, follow the heads)
+        HIP_TRY(hipMalloc((void**)&P.heads, (((headWords + 1) & ~size_t(1)) + 2 * headWords) * sizeof(uint32_t)));
         P.headWords = headWords;
     }
     if (growPools) {
@@ -3268,7 +3295,27 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         HIP_TRY(hipMemsetAsync(D.heads, 0xff, size_t(outPixels) * size_t(A.samples) * sizeof(uint32_t), c->stream));
         HIP_TRY(hipMemsetAsync(D.counters, 0, kDeferControlWords * sizeof(uint32_t), c->stream));
         if (stats)
-            HIP_TRY(hipEventRecord(c->ev0, c->stream)); // kernel_ms covers the three passes
+            HIP_TRY(hipEventRecord(c->ev0, c->stream)); // kernel_ms covers the passes
+        // A walk that holds one or two pixels per wave (deep glossy trees) would trace each camera
+        // ray with a lane or two: a camera pass traces them a full wave of pixels at a time first
+        // -- the same query per ray, so the same hits -- and the walk picks them up.  (Measured on
+        // the glossy depth 4 frame: 14.1 -> 12.9 ms per frame with two frames in flight, 17.7 ->
+        // 17.9 ms alone; with eight pixels per wave, depth 2, it cost 7 % and is not taken.)
+        if (scene->d.nSpheres == 0 && A.pixelsPerUnit * A.lanesPerPixel <= 2 && A.pixelsPerUnit < mostPixelsPerUnit && !getenv("RTX_NO_CAMERA_PASS")) {
+            A.defer.primary = reinterpret_cast<uint2*>(c->defer.heads + ((c->defer.headWords + 1) & ~size_t(1)));
+            RenderArgs Cm = A;
+            Cm.pixelsPerUnit = mostPixelsPerUnit;
+            Cm.unitsPerBlockLog2 = 0;
+            while ((Cm.pixelsPerUnit << Cm.unitsPerBlockLog2) < 64)
+                Cm.unitsPerBlockLog2++;
+            Cm.work = makeQueue(c, a, uint32_t((seqPixels + Cm.pixelsPerUnit - 1) / Cm.pixelsPerUnit));
+            Cm.blockOrder = nullptr; // (list order, nothing measured: the pass is short)
+            Cm.blockCost = nullptr;
+            Cm.costFloor = 0;
+            launch(Cm, 9, 0);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemsetAsync(a->tickets, 0, kTicketBytes, c->stream)); // the work queue starts over for the walk
+        }
         launch(A, 4, walkLds);
         HIP_TRY(hipGetLastError());
         uint32_t slot = 0, offset = 0;
