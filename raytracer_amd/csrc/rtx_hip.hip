@@ -2105,30 +2105,39 @@ RTX_DEV V3 resolveTape(const Deferred& D, uint32_t head)
     int32_t count[kMaxDepth];
     int level = 0;
     uint32_t at = (head - 1) * kTapeChunk;
+    // The replay of a deep sample (hundreds of entries) is a chain of dependent loads, entry
+    // after entry and each entry's lights after it: the next entry of the chunk is fetched while
+    // this one's lights are (a chunk's last entry is a link or the sample's end, so at + 1 stays
+    // inside the chunk whenever its value is used).
+    TapeEntry e = D.tape[at];
     for (;;) {
-        const TapeEntry e = D.tape[at];
         if (e.op == TAPE_LINK) {
             at = e.point * kTapeChunk;
+            e = D.tape[at];
             continue;
         }
+        const TapeEntry cur = e;
         at++;
-        V3 value = mk(e.a);
-        if (e.op == TAPE_HIT || e.op == TAPE_OPEN) {
+        const bool ends = (level == 0 && cur.op != TAPE_OPEN) || (level == 1 && cur.op == TAPE_CLOSE); // (the sample's last entry: nothing of it lies behind)
+        if (!ends)
+            e = D.tape[at];
+        V3 value = mk(cur.a);
+        if (cur.op == TAPE_HIT || cur.op == TAPE_OPEN) {
             // Lo: the lights in scene order (src/light.cpp:146-181)
-            if (e.point != kNoPoint) {
-                const float* c = D.contrib + size_t(e.point) * D.nCounting * 3;
+            if (cur.point != kNoPoint) {
+                const float* c = D.contrib + size_t(cur.point) * D.nCounting * 3;
                 for (uint32_t j = 0; j < D.nCounting; j++)
                     value = value + mk(c + 3 * j);
             }
-            if (e.op == TAPE_OPEN) {
+            if (cur.op == TAPE_OPEN) {
                 Lo[level] = value;
-                ks[level] = mk(e.ks);
+                ks[level] = mk(cur.ks);
                 acc[level] = mk(0, 0, 0);
                 count[level] = 0;
                 level++;
                 continue;
             }
-        } else if (e.op == TAPE_CLOSE) {
+        } else if (cur.op == TAPE_CLOSE) {
             // color *= 1/count (0 * inf = NaN when no child was followed), Lo + color * ks
             level--;
             const V3 color = acc[level] * (1.0f / float(count[level]));
