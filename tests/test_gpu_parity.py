@@ -360,6 +360,10 @@ def test_origin_frames_do_not_change_frames(gpu_device, monkeypatch):
     many = dragon_scene(subdivisions=3)
     many.lights = [abi.point_light((np.cos(a), 1.0, np.sin(a)), (0.2, 0.2, 0.2)) for a in np.linspace(0, 5, 6)]
     scenes.append(("six point lights", many, False))
+    with_spheres = dragon_scene(subdivisions=3)      # (spheres are tested per ray, before the walk, on either kind of record)
+    with_spheres.add_sphere((0.9, 0.2, -0.4), 0.3, (0.2, 0.7, 0.3, 0.0, 0.0, 0.0, 1.0, 1.0))
+    with_spheres.add_sphere((-0.2, 0.1, 1.1), 0.15, (0.7, 0.2, 0.3, 0.0, 0.0, 0.0, 1.0, 1.0))
+    scenes.append(("triangles and spheres", with_spheres, False))
     cams = [make_camera(), make_camera(distance=1.4, rotation_degrees=(35, -50, 0)), make_camera(look_at=(0.2, 0.1, 0.0)), make_camera()]
     f = abi.features(**cases.BASE)
     rp = make_params(200, 120, driver=abi.DRIVER_MRAYS, samples=8)
@@ -377,6 +381,11 @@ def test_origin_frames_do_not_change_frames(gpu_device, monkeypatch):
         monkeypatch.delenv("RTX_NO_ORIGIN_FRAMES")
         assert np.array_equal(_bits(got[0][0]), _bits(got[3][0])) and got[0][1][1] > 0 and np.nanmax(got[0][0]) > 0
         assert not np.array_equal(_bits(got[0][0]), _bits(got[1][0]))
+        if scene.spheres:   # and against the oracle, at a size it renders in a moment
+            small = make_params(80, 48, driver=abi.DRIVER_MRAYS, samples=4)
+            orc = OracleEngine(scene, f)
+            assert_images_close(gpu.render(cams[1], f, small), orc.render(cams[1], f, small), name)
+            orc.close()
         gpu.close()
 
 
