@@ -912,6 +912,36 @@ def test_multi_rank_code_path_through_rccl_on_one_gpu(gpu_device):
     assert line["n_gpus"] == 1 and line["config"]["partition"].startswith("interleaved") and line["value"] > 0
 
 
+@pytest.mark.parametrize("workload,ranks", [("headline", 2), ("area_glossy", 3)])
+def test_several_ranks_rehearsed_on_one_gpu(gpu_device, workload, ranks):
+    """bench.py as the driver launches it for N > 1 (python -m torch.distributed.run, one process
+    per rank), rehearsed on ONE GPU: every rank renders its interleaved tiles there with two
+    frames in flight, the tiles are gathered over gloo (staged through the host: RCCL wants a GPU
+    per rank), rank 0 assembles each frame and holds both slots' frames to the single-GPU frame,
+    bit for bit (NaN pixels of the glossy workload included)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--single-device", "--check",
+                        "--workload", workload, "--steps", "4", "--warmup", "2", "--width", "640", "--height", "360"],
+                       capture_output=True, text=True, timeout=115, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "check ok: the assembled frame of each of 2 slot(s)" in r.stderr
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == ranks and line["config"]["frames_in_flight"] == 2 and line["value"] > 0
+    assert line["config"]["rays_per_frame"] == line["config"]["primary"] + line["config"]["shadow"] + line["config"]["bounce"]
+
+
 def test_render_into_page_locked_host_memory(gpu_device):
     """rtx_render into a buffer from rtx_host_alloc gives the frame it gives into plain host
     memory (the copy back takes the direct path instead of the runtime's staging buffer)."""
