@@ -4,6 +4,7 @@
 // BvhInterface::intersect becomes a one-ray rtx_trace.
 #include "rtx_binding.h"
 
+#include <atomic>
 #include <cstring>
 #include <stdexcept>
 
@@ -124,10 +125,20 @@ rtx_features toRtx(const Features& f)
 
 rtx_scene* deviceSceneOf(const BvhInterface& bvh) { return (bvh.*memberOf(BvhImpl()))->dev; }
 
+void bindThisThread()
+{
+    thread_local bool bound = false;
+    if (bound)
+        return;
+    static std::atomic<int> nextSlot { 0 };
+    if (rtx_init(0) != RTX_OK || rtx_select_slot(nextSlot++ % RTX_FRAME_SLOTS) != RTX_OK)
+        throw std::runtime_error(rtx_last_error());
+    bound = true;
+}
+
 BvhInterface::BvhInterface(Scene* pScene, const Features& features)
 {
-    if (rtx_init(0) != RTX_OK)
-        throw std::runtime_error(rtx_last_error());
+    bindThisThread();
     rt::Features rf;
     rf.enableShading = features.enableShading, rf.enableRecursive = features.enableRecursive, rf.enableHardShadow = features.enableHardShadow;
     rf.enableSoftShadow = features.enableSoftShadow, rf.enableNormalInterp = features.enableNormalInterp;
@@ -164,6 +175,7 @@ bool BvhInterface::intersect(Ray& ray, HitInfo& hitInfo, const Features& feature
     r.t = ray.t;
     rtx_hit h;
     const rtx_features f = toRtx(features);
+    bindThisThread();
     if (rtx_trace(m_impl->dev, &r, 1, &h, &f, nullptr) != RTX_OK)
         throw std::runtime_error(rtx_last_error());
     if (!h.hit)

@@ -16,10 +16,13 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -200,6 +203,37 @@ try {
         default: throw std::runtime_error("unknown driver");
         }
         out.write(reinterpret_cast<const char*>(screen.pixels().data()), std::streamsize(screen.pixels().size() * sizeof(glm::vec3)));
+        // The reference's command line renders every camera on a thread of its own
+        // (src/main.cpp:560-563): the same frame from three such threads at once must be the
+        // frame above, bit for bit.  (Not the motion-blur driver, which keeps state between calls.)
+        if (driver != 4) {
+            std::vector<Screen> again(3, Screen(glm::ivec2(W, H), false));
+            std::vector<std::thread> workers;
+            std::string failure;
+            std::mutex guard;
+            for (Screen& s : again)
+                workers.emplace_back([&, target = &s] {
+                    try {
+                        Trackball cameraOfThread(reinterpret_cast<Window*>(&aspect), cam.fovy, cam.lookAt, cam.distance, cam.rotation.x, cam.rotation.y);
+                        switch (driver) {
+                        case 0: renderRayTracing(scene, cameraOfThread, bvh, *target, features); break;
+                        case 1: samples > 0 ? renderRayTracingMRaysPerPixel(scene, cameraOfThread, bvh, *target, features, samples) : renderRayTracingMRaysPerPixel(scene, cameraOfThread, bvh, *target, features); break;
+                        case 2: renderRayTracingDepthOfField(scene, cameraOfThread, bvh, *target, features, aperture, focal, samples); break;
+                        default: renderRayTracingTransparency(scene, cameraOfThread, bvh, *target, features); break;
+                        }
+                    } catch (const std::exception& e) {
+                        std::lock_guard<std::mutex> lock(guard);
+                        failure = e.what();
+                    }
+                });
+            for (std::thread& w : workers)
+                w.join();
+            if (!failure.empty())
+                throw std::runtime_error("on a thread of its own: " + failure);
+            for (const Screen& s : again)
+                if (std::memcmp(s.pixels().data(), screen.pixels().data(), screen.pixels().size() * sizeof(glm::vec3)) != 0)
+                    throw std::runtime_error("the frame rendered on a thread of its own differs from the first");
+        }
     } else {
         std::ifstream rin(raysPath, std::ios::binary);
         rin.seekg(0, std::ios::end);

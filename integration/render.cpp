@@ -51,6 +51,7 @@ void run(const BvhInterface& bvh, const Trackball& camera, Screen& screen, const
     const rtx_camera c = toRtx(camera);
     const rtx_features f = toRtx(features);
     // Screen::pixels() is row 0 = top, three packed floats per pixel: exactly what rtx_render writes
+    bindThisThread();
     if (rtx_render(deviceSceneOf(bvh), &c, &f, &p, &screen.pixels()[0].x, nullptr) != RTX_OK)
         throw std::runtime_error(rtx_last_error());
 }
@@ -122,6 +123,7 @@ glm::vec3 getFinalColor(const Scene&, const BvhInterface& bvh, Ray ray, const Fe
     p.seed = 1;
     const rtx_features f = toRtx(features);
     glm::vec3 out;
+    bindThisThread();
     if (rtx_shade(deviceSceneOf(bvh), &r, 1, &f, &p, &out.x, nullptr) != RTX_OK) // (n rays per call for batches)
         throw std::runtime_error(rtx_last_error());
     return out;

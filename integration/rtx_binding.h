@@ -32,3 +32,9 @@ struct PrivateMember {
 rtx_features toRtx(const Features& features);
 rtx_camera toRtx(const Trackball& camera);
 rtx_scene* deviceSceneOf(const BvhInterface& bvh);
+// Binds the calling thread to the GPU on its first call through the binding.  The reference's
+// command line renders every camera on a thread of its own (src/main.cpp:560-563) and its
+// viewer intersects from OpenMP threads: the thread that constructs the BvhInterface works in
+// frame slot 0, each further thread in the next slot in turn, so that the cameras' frames share
+// the GPU instead of queueing behind one another.  Throws std::runtime_error without a GPU.
+void bindThisThread();
