@@ -240,7 +240,10 @@ int rtx_init(int device);
 
 /* Upload a flattened scene once.  Replaces the tail of
  * BvhInterface::BvhInterface (src/bvh_interface.cpp:6-9): the host has built
- * the tree, this copies it to HBM.  Returns NULL on failure. */
+ * the tree, this copies it to HBM.  Returns NULL on failure.
+ * Beside the records as given the scene keeps, for each point light among its first four, a copy
+ * of the traversal records relative to the light's position (the shadow rays of such a light all
+ * start there; about twice the size of the triangle records per light), made by a kernel here. */
 rtx_scene* rtx_scene_create(const rtx_scene_desc* desc);
 /* The same scene with its tree built on the GPU instead.  Replaces the whole of
  * BoundingVolumeHierarchy's constructor and bvhSplitHelper
