@@ -363,6 +363,14 @@ int rtx_streams_overlap(void* hip_stream_a, void* hip_stream_b);
 void* rtx_host_alloc(size_t bytes);
 void  rtx_host_free(void* buffer);
 
+/* Self-check of the device's sine and cosine.  The motion-blur driver builds one camera per sample
+ * from interpolated Euler angles (src/render.cpp:203-247, glm::quat(euler)), whose sines and
+ * cosines the reference takes from the host C library; the device computes them by a
+ * restatement of that library's routine, and this call returns what it gives for n arguments
+ * (device pointers, n floats each) so that a test can hold them to the host's, bit for bit.
+ * Runs in this thread's frame slot, on its stream; waits for the result. */
+int rtx_selfcheck_trig(const float* x_device, size_t n, float* sin_device, float* cos_device);
+
 /* Block until all work queued in this thread's frame slot has finished. */
 int rtx_synchronize(void);
 

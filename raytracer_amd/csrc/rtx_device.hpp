@@ -1318,13 +1318,78 @@ RTX_DEV V3 rotate(float qw, V3 qv, V3 v)
     const V3 uuv = cross(qv, uv);
     return v + ((uv * qw) + uuv) * 2.0f;
 }
-// glm::quat(euler), glm/detail/type_quat.inl:208-217 (device trig: used only by
+// sinf / cosf with the host C library's results.  glm::quat(euler) calls std::sin / std::cos on
+// floats, which on the hosts this runs beside is glibc's sinf / cosf (2.35,
+// sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, sincosf_data.c: the algorithm of Arm's
+// optimized routines): the argument is reduced and a degree-7 / degree-8 polynomial evaluated in
+// double, the result rounded to float once.  Its error is below 0.6 ulp but it is not the
+// correctly rounded value, and the device library's sinf / cosf round differently in about one
+// argument in ten: a motion-blur sample's camera then differs in its last bit and its ray
+// crosses a silhouette on the other side.  Restated here with the same coefficients and, as in
+// the variant glibc runs on a CPU with fused multiply-add, one rounding per multiply-add:
+// 749 million arguments below 120 in magnitude (every third float) give the host's bits without
+// exception.  Arguments of 120 and beyond (nineteen turns of the camera) take the device
+// library's routine.
+struct HostTrig {
+    static constexpr double hpiInv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    static constexpr double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    static constexpr double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    static __device__ __forceinline__ uint32_t top12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
+    // sine (n even) or cosine (n odd) of the reduced argument; `flip`: the cosine's sign in the
+    // second half of the turn (glibc keeps a second table with the cosine's coefficients negated)
+    static __device__ __forceinline__ float poly(double x, double x2, int n, bool flip)
+    {
+        if ((n & 1) == 0) {
+            const double x3 = x * x2;
+            const double t = __builtin_fma(x2, s3, s2);
+            const double x7 = x3 * x2;
+            const double s = __builtin_fma(x3, s1, x);
+            return float(__builtin_fma(x7, t, s));
+        }
+        const double sg = flip ? -1.0 : 1.0; // (an exact negation of every coefficient, hence of every intermediate)
+        const double x4 = x2 * x2;
+        const double h = __builtin_fma(x2, sg * c4, sg * c3);
+        const double l = __builtin_fma(x2, sg * c1, sg * c0);
+        const double x6 = x4 * x2;
+        const double c = __builtin_fma(x4, sg * c2, l);
+        return float(__builtin_fma(x6, h, c));
+    }
+    // quarter turns in y, and what is left of it (|y| < 120: the product fits the conversion)
+    static __device__ __forceinline__ double reduce(double x, int& n)
+    {
+        const double r = x * hpiInv;
+        n = (int32_t(r) + 0x800000) >> 24;
+        return __builtin_fma(-double(n), hpi, x);
+    }
+    static __device__ __forceinline__ float sinCos(float y, int cosine)
+    {
+        double x = double(y);
+        if (top12(y) < top12(0x1.921FB6p-1f)) { // |y| below pi / 4
+            if (top12(y) < top12(0x1p-12f))
+                return cosine ? 1.0f : y;
+            return poly(x, x * x, cosine, false);
+        }
+        int n;
+        x = reduce(x, n);
+        const double sign = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        return poly(x * sign, x * x, n ^ cosine, (n & 2) != 0);
+    }
+};
+RTX_DEV float hostSinf(float y)
+{
+    return HostTrig::top12(y) < HostTrig::top12(120.0f) ? HostTrig::sinCos(y, 0) : sinf(y);
+}
+RTX_DEV float hostCosf(float y)
+{
+    return HostTrig::top12(y) < HostTrig::top12(120.0f) ? HostTrig::sinCos(y, 1) : cosf(y);
+}
+// glm::quat(euler), glm/detail/type_quat.inl:208-217 (on the device: used only by
 // the motion-blur driver, whose per-sample cameras cannot be prepared on the host)
 RTX_DEV void quatFromEuler(V3 e, float& qw, V3& qv)
 {
     const V3 h = e * 0.5f;
-    const V3 c = mk(cosf(h.x), cosf(h.y), cosf(h.z));
-    const V3 s = mk(sinf(h.x), sinf(h.y), sinf(h.z));
+    const V3 c = mk(hostCosf(h.x), hostCosf(h.y), hostCosf(h.z));
+    const V3 s = mk(hostSinf(h.x), hostSinf(h.y), hostSinf(h.z));
     qw = c.x * c.y * c.z + s.x * s.y * s.z;
     qv = mk(s.x * c.y * c.z - c.x * s.y * s.z, c.x * s.y * c.z + s.x * c.y * s.z, c.x * c.y * s.z - s.x * s.y * c.z);
 }

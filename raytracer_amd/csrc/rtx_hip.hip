@@ -3547,6 +3547,16 @@ int uploadShading(rtx_scene* s, const rtx_scene_desc* d)
 }
 
 // Keeps one wave busy for `ticks` of the 100 MHz wall clock (streamsOverlap).
+// the device's restatement of the host library's sinf / cosf, for rtx_selfcheck_trig
+__global__ void __launch_bounds__(256) trigKernel(const float* x, uint32_t n, float* sinOut, float* cosOut)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) {
+        sinOut[i] = rtxd::hostSinf(x[i]);
+        cosOut[i] = rtxd::hostCosf(x[i]);
+    }
+}
+
 __global__ void __launch_bounds__(64) spinKernel(unsigned long long ticks)
 {
     const unsigned long long t0 = wall_clock64();
@@ -4571,6 +4581,24 @@ int rtx_set_stream(void* hipStream)
         HIP_TRY(hipStreamWaitEvent(next, c->evSwitch, 0));
         c->stream = next;
     }
+    return RTX_OK;
+}
+
+int rtx_selfcheck_trig(const float* x, size_t n, float* sinOut, float* cosOut)
+{
+    if (int rc = checkCtx(nullptr))
+        return rc;
+    if (n > (size_t(1) << 30) || (n && (!x || !sinOut || !cosOut))) {
+        setErr("rtx_selfcheck_trig: %zu arguments (at most 2^30), or a null array", n);
+        return RTX_ERR_INVALID;
+    }
+    DeviceCtx* c = g_ctx;
+    std::lock_guard<std::mutex> launchLock(c->launch);
+    if (n) {
+        hipLaunchKernelGGL(trigKernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, c->stream, x, uint32_t(n), sinOut, cosOut);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return RTX_OK;
 }
 

@@ -1,0 +1,157 @@
+"""Seeded random scenes against the oracle: triangle soups of unrelated sizes (no mesh
+structure for the tree builder to lean on, leaves that overlap, slivers, zero-area
+triangles), spheres among them, lights inside and outside the geometry, cameras outside
+and inside it, under every driver.  Bars as in test_gpu_parity.py: ray queries bit-exact,
+frames within 1e-3 with NaN pixels in the same places, identical ray counts.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from raytracer_amd import abi
+from raytracer_amd.engine import GpuEngine
+from raytracer_amd.scene import SceneData, make_camera, make_params
+from oracle.bindings import OracleEngine
+from test_gpu_parity import assert_hits_equal, assert_images_close
+
+pytestmark = pytest.mark.gpu
+
+
+def soup(rng, n, spread, size, degenerate=0.03):
+    """n unconnected triangles: centres within `spread` of the origin, edges up to `size`;
+    vertex normals near the face normal; a few triangles with two equal corners."""
+    c = (rng.random((n, 1, 3)) * 2 - 1) * spread
+    p = c + (rng.random((n, 3, 3)) * 2 - 1) * (size * rng.random((n, 1, 1)) ** 2 + 0.01)
+    # slivers: the third corner almost on the line through the other two
+    thin = rng.random(n) < 0.1
+    p[thin, 2] = p[thin, 0] + (p[thin, 1] - p[thin, 0]) * 0.5 + (rng.random((int(thin.sum()), 3)) - 0.5) * 1e-3
+    same = rng.random(n) < degenerate
+    p[same, 2] = p[same, 1]
+    p = p.astype(np.float32)
+    fn = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    ln = np.linalg.norm(fn, axis=1, keepdims=True)
+    fn = np.where(ln > 0, fn / np.where(ln > 0, ln, 1), (0, 1, 0))
+    vn = fn[:, None, :] + (rng.random((n, 3, 3)) - 0.5) * 0.6
+    vn /= np.linalg.norm(vn, axis=2, keepdims=True)
+    v = np.zeros((n * 3, 8), np.float32)
+    v[:, 0:3] = p.reshape(-1, 3)
+    v[:, 3:6] = vn.reshape(-1, 3)
+    v[:, 6:8] = rng.random((n * 3, 2))
+    return v, np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(1000 + seed)
+    s = SceneData()
+    for n in rng.choice([7, 60, 200, 500], size=int(rng.integers(1, 4))):
+        kd = rng.random(3)
+        ks = rng.random(3) * (rng.random() < 0.4)
+        transparency = 1.0 if rng.random() < 0.5 else 0.3 + 0.6 * rng.random()
+        v, t = soup(rng, int(n), spread=0.3 + 0.4 * rng.random(), size=0.2 + 0.6 * rng.random())
+        s.add_mesh(v, t, (*kd, *ks, 1.0 + 60.0 * rng.random(), transparency))
+    for _ in range(int(rng.integers(0, 3))):
+        s.add_sphere((rng.random(3) * 2 - 1) * 0.7, 0.05 + 0.25 * rng.random(), (*rng.random(3), *(rng.random(3) * 0.5 * (rng.random() < 0.5)), 20.0, 1.0))
+    for _ in range(int(rng.integers(1, 3))):
+        d = rng.normal(size=3)
+        s.lights.append(abi.point_light(d / np.linalg.norm(d) * (0.2 + 2.5 * rng.random()), 0.4 + 0.6 * rng.random(3)))
+    return s, rng
+
+
+def random_camera(rng, distance=None):
+    return make_camera(fov_degrees=35.0 + 25.0 * rng.random(), distance=distance if distance is not None else 1.3 + 1.2 * rng.random(),
+                       look_at=tuple((rng.random(3) - 0.5) * 0.4), rotation_degrees=(rng.random() * 360 - 180, rng.random() * 360, 0))
+
+
+def check_frame(gpu, orc, cam, f, rp, what):
+    got = gpu.render(cam, f, rp)
+    counts = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
+    want = orc.render(cam, f, rp)
+    if gpu.stats.layer_overflows:
+        # the device follows 16 translucent layers per camera ray and reports the rays that met a
+        # 17th (the reference recurses without a bound, src/transparency.cpp:6-20): such a frame
+        # traces fewer rays than the reference's and is not held to it
+        assert rp.driver == abi.DRIVER_TRANSPARENCY and counts[0] < int(orc.counters[0])
+        return
+    assert_images_close(got, want, what)
+    assert counts == tuple(int(x) for x in orc.counters[:3]), f"{what}: ray counts {counts} vs oracle {tuple(orc.counters[:3])}"
+
+
+# (RTX_FUZZ_SEEDS=1000 for a longer hunt)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTX_FUZZ_SEEDS", "48"))))
+def test_random_soups_under_every_driver(gpu_device, seed):
+    scene, rng = random_scene(seed)
+    outside, outside2, inside = random_camera(rng), random_camera(rng), random_camera(rng, distance=0.15)
+    base = abi.features(**cases.BASE)
+    mirror = abi.features(**dict(cases.BASE, recursive=1))
+    gpu, orc = GpuEngine(scene, base), OracleEngine(scene, base)
+    # ray queries: the tree walk alone, on rays of every kind
+    rays = cases.ray_batch(scene, seed, n_random=3000, grid=32)
+    assert_hits_equal(gpu.intersect(rays, base), orc.intersect(rays, base), f"soup {seed} rays")
+    for cam, name in ((outside, "outside"), (inside, "inside")):
+        check_frame(gpu, orc, cam, base, make_params(64, 36), f"soup {seed} {name}, plain")
+        check_frame(gpu, orc, cam, mirror, make_params(48, 27, ray_depth=3), f"soup {seed} {name}, mirrors to depth 3")
+        check_frame(gpu, orc, cam, base, make_params(48, 27, driver=abi.DRIVER_MRAYS, samples=4), f"soup {seed} {name}, 4 samples")
+    # (most of a soup lies in some triangle's shadow: without shadows every hit's shading counts)
+    unshadowed = abi.features(shading=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1, recursive=1)
+    check_frame(gpu, orc, outside, unshadowed, make_params(64, 36), f"soup {seed}, no shadows")
+    check_frame(gpu, orc, outside2, unshadowed, make_params(48, 27, driver=abi.DRIVER_MRAYS, samples=3), f"soup {seed}, no shadows, 3 samples")
+    # few pixels against many triangles: the frame's rays no longer run side by side
+    check_frame(gpu, orc, outside2, base, make_params(24, 14), f"soup {seed}, 24x14")
+    check_frame(gpu, orc, outside2, base, make_params(40, 22, driver=abi.DRIVER_DOF, samples=4, aperture=0.08, focal_length=2.0), f"soup {seed}, depth of field")
+    check_frame(gpu, orc, outside, mirror, make_params(40, 22, driver=abi.DRIVER_MOTION_BLUR, samples=3, prev_camera=outside2), f"soup {seed}, motion blur")
+    check_frame(gpu, orc, outside, mirror, make_params(48, 27, driver=abi.DRIVER_TRANSPARENCY), f"soup {seed}, transparency")
+    gpu.close()
+    orc.close()
+    # the other tree (median split, flat normals) and no tree at all
+    for feat in (dict(shading=1, hard_shadow=1, accel_structure=1), dict(shading=1, hard_shadow=1, normal_interp=1)):
+        f = abi.features(**feat)
+        gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+        assert_hits_equal(gpu.intersect(rays[:1500], f), orc.intersect(rays[:1500], f), f"soup {seed} rays, {feat}")
+        check_frame(gpu, orc, outside, f, make_params(40, 22), f"soup {seed}, {feat}")
+        gpu.close()
+        orc.close()
+    # area lights: a segment and a parallelogram, glossy reflections to depth 2
+    soft = abi.features(**dict(cases.BASE, hard_shadow=0, soft_shadow=1, recursive=1, glossy_reflection=1))
+    scene.lights = [abi.segment_light((-0.5, 1.0, 0.2), (0.5, 1.1, -0.2), (1, 0.8, 0.6), (0.6, 0.8, 1)),
+                    abi.parallelogram_light((0.9, -0.2, -0.2), (0, 0.4, 0), (0, 0, 0.4), (1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1))]
+    gpu, orc = GpuEngine(scene, soft), OracleEngine(scene, soft)
+    check_frame(gpu, orc, outside, soft, make_params(40, 22, shadow_samples=6, glossy_rays=2, ray_depth=2), f"soup {seed}, area lights + glossy")
+    check_frame(gpu, orc, inside, soft, make_params(32, 18, driver=abi.DRIVER_MRAYS, samples=2, shadow_samples=3, glossy_rays=2, ray_depth=1), f"soup {seed}, area lights from inside")
+    gpu.close()
+    orc.close()
+
+
+def test_device_sine_and_cosine_are_the_host_librarys(gpu_device):
+    """The motion-blur driver's per-sample cameras come from glm::quat(euler) (src/render.cpp:203-247),
+    that is from the host C library's sinf / cosf: the device's restatement of that routine must
+    give its bits.  Checked on half-angles a camera can have (every float pattern in steps over
+    +-2 pi, densely around the multiples of pi / 4 where the routine changes branch) and up to the
+    routine's range of +-120."""
+    import ctypes as C
+    import ctypes.util
+    import torch
+    from raytracer_amd import engine
+    lib = engine.hip_lib()
+    assert lib.rtx_init(0) == 0
+    libm = C.CDLL(ctypes.util.find_library("m"))
+    libm.sinf.restype = libm.cosf.restype = C.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [C.c_float]
+    rng = np.random.default_rng(11)
+    top = np.float32(2 * np.pi).view(np.uint32)
+    bits = np.arange(0, int(top), 9973, dtype=np.uint32)                      # positive floats up to 2 pi
+    near = np.concatenate([(np.float32(k * np.pi / 4).view(np.uint32) + np.arange(-300, 301)).astype(np.uint32) for k in range(1, 40)])
+    x = np.concatenate([bits.view(np.float32), near.view(np.float32), (rng.random(60000) * 120).astype(np.float32),
+                        np.array([0.0, 1e-30, 2.0 ** -12, np.nextafter(np.float32(2.0 ** -12), np.float32(0)), 119.99999], np.float32)])
+    x = np.concatenate([x, -x])
+    assert np.abs(x).max() < 120 and len(x) > 250000
+    dx = torch.from_numpy(x).cuda()
+    ds, dc = torch.empty_like(dx), torch.empty_like(dx)
+    assert lib.rtx_selfcheck_trig(C.c_void_p(dx.data_ptr()), C.c_size_t(len(x)), C.c_void_p(ds.data_ptr()), C.c_void_p(dc.data_ptr())) == 0, lib.rtx_last_error()
+    want_s = np.array([libm.sinf(float(v)) for v in x], np.float32)
+    want_c = np.array([libm.cosf(float(v)) for v in x], np.float32)
+    bad_s = np.flatnonzero(ds.cpu().numpy().view(np.uint32) != want_s.view(np.uint32))
+    bad_c = np.flatnonzero(dc.cpu().numpy().view(np.uint32) != want_c.view(np.uint32))
+    assert len(bad_s) == 0, f"sinf differs for {len(bad_s)} arguments, first {x[bad_s[:4]]}"
+    assert len(bad_c) == 0, f"cosf differs for {len(bad_c)} arguments, first {x[bad_c[:4]]}"
