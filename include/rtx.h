@@ -363,13 +363,17 @@ int rtx_streams_overlap(void* hip_stream_a, void* hip_stream_b);
 void* rtx_host_alloc(size_t bytes);
 void  rtx_host_free(void* buffer);
 
-/* Self-check of the device's sine and cosine.  The motion-blur driver builds one camera per sample
- * from interpolated Euler angles (src/render.cpp:203-247, glm::quat(euler)), whose sines and
- * cosines the reference takes from the host C library; the device computes them by a
- * restatement of that library's routine, and this call returns what it gives for n arguments
- * (device pointers, n floats each) so that a test can hold them to the host's, bit for bit.
- * Runs in this thread's frame slot, on its stream; waits for the result. */
-int rtx_selfcheck_trig(const float* x_device, size_t n, float* sin_device, float* cos_device);
+/* Self-check of the device's trigonometry.  Two places of the path turn an angle into a discrete
+ * outcome: the motion-blur driver builds one camera per sample from interpolated Euler angles
+ * (src/render.cpp:203-247, glm::quat(euler)), and the environment map turns a direction into
+ * texture coordinates (src/environment_mapping.cpp:130-207).  The reference takes the sines,
+ * cosines, tangents, arc cosines and arc tangents there from the host C library; the device
+ * computes them by restatements of that library's routines, and this call returns what they
+ * give: for i < n, out[i] = sin(x[i]), out[n + i] = cos(x[i]), out[2n + i] = tan(x[i]),
+ * out[3n + i] = acos(x[i]), out[4n + i] = atan2(y[i], x[i]) (device pointers; out holds 5 n
+ * floats), so that a test can hold them to the host's, bit for bit.  Runs in this thread's frame
+ * slot, on its stream; waits for the result.  No counterpart in the reference. */
+int rtx_selfcheck_trig(const float* x_device, const float* y_device, size_t n, float* out_device);
 
 /* Block until all work queued in this thread's frame slot has finished. */
 int rtx_synchronize(void);

@@ -1073,6 +1073,240 @@ RTX_DEV V3 texelTrilinear(const DScene& sc, const rtx_texture& tx, V3 ro, V3 rd,
     return a * c0 + (1 - a) * c1;
 }
 
+// --------------------------------------- the host library's trigonometry ----
+// sinf / cosf with the host C library's results.  glm::quat(euler) calls std::sin / std::cos on
+// floats, which on the hosts this runs beside is glibc's sinf / cosf (2.35,
+// sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, sincosf_data.c: the algorithm of Arm's
+// optimized routines): the argument is reduced and a degree-7 / degree-8 polynomial evaluated in
+// double, the result rounded to float once.  Its error is below 0.6 ulp but it is not the
+// correctly rounded value, and the device library's sinf / cosf round differently in about one
+// argument in ten: a motion-blur sample's camera then differs in its last bit and its ray
+// crosses a silhouette on the other side.  Restated here with the same coefficients and, as in
+// the variant glibc runs on a CPU with fused multiply-add, one rounding per multiply-add:
+// 749 million arguments below 120 in magnitude (every third float) give the host's bits without
+// exception.  Arguments of 120 and beyond (nineteen turns of the camera) take the device
+// library's routine.
+struct HostTrig {
+    static constexpr double hpiInv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    static constexpr double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    static constexpr double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    static __device__ __forceinline__ uint32_t top12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
+    // sine (n even) or cosine (n odd) of the reduced argument; `flip`: the cosine's sign in the
+    // second half of the turn (glibc keeps a second table with the cosine's coefficients negated)
+    static __device__ __forceinline__ float poly(double x, double x2, int n, bool flip)
+    {
+        if ((n & 1) == 0) {
+            const double x3 = x * x2;
+            const double t = __builtin_fma(x2, s3, s2);
+            const double x7 = x3 * x2;
+            const double s = __builtin_fma(x3, s1, x);
+            return float(__builtin_fma(x7, t, s));
+        }
+        const double sg = flip ? -1.0 : 1.0; // (an exact negation of every coefficient, hence of every intermediate)
+        const double x4 = x2 * x2;
+        const double h = __builtin_fma(x2, sg * c4, sg * c3);
+        const double l = __builtin_fma(x2, sg * c1, sg * c0);
+        const double x6 = x4 * x2;
+        const double c = __builtin_fma(x4, sg * c2, l);
+        return float(__builtin_fma(x6, h, c));
+    }
+    // quarter turns in y, and what is left of it (|y| < 120: the product fits the conversion)
+    static __device__ __forceinline__ double reduce(double x, int& n)
+    {
+        const double r = x * hpiInv;
+        n = (int32_t(r) + 0x800000) >> 24;
+        return __builtin_fma(-double(n), hpi, x);
+    }
+    static __device__ __forceinline__ float sinCos(float y, int cosine)
+    {
+        double x = double(y);
+        if (top12(y) < top12(0x1.921FB6p-1f)) { // |y| below pi / 4
+            if (top12(y) < top12(0x1p-12f))
+                return cosine ? 1.0f : y;
+            return poly(x, x * x, cosine, false);
+        }
+        int n;
+        x = reduce(x, n);
+        const double sign = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        return poly(x * sign, x * x, n ^ cosine, (n & 2) != 0);
+    }
+};
+RTX_DEV float hostSinf(float y)
+{
+    return HostTrig::top12(y) < HostTrig::top12(120.0f) ? HostTrig::sinCos(y, 0) : sinf(y);
+}
+RTX_DEV float hostCosf(float y)
+{
+    return HostTrig::top12(y) < HostTrig::top12(120.0f) ? HostTrig::sinCos(y, 1) : cosf(y);
+}
+// atan2f, acosf and tanf of the same library, which the environment map's lookup turns a direction
+// into texture coordinates with (src/environment_mapping.cpp:167-207): a last-bit difference there
+// picks the neighbouring texel once in ten thousand lookups of a 4096-texel-wide map.  These are
+// glibc 2.35's e_atan2f.c / s_atanf.c / e_acosf.c / k_tanf.c (the float forms of Sun's fdlibm:
+// argument reduction to a short interval, an odd polynomial or a rational function, all in float)
+// and, for tanf's argument, the quarter-turn reduction in double that s_sinf.c uses, split into a
+// float head and tail (e_rem_pio2f.c).  Every operation is a single IEEE float operation in the
+// order written there; 1.4 billion arguments of atanf, 1.07 billion of acosf, 400 million pairs of
+// atan2f and all 2.2 billion floats below 120 in magnitude of tanf give the host's bits on the CPU.
+RTX_DEV float hostAtanf(float x)
+{
+    const int32_t hx = __float_as_int(x), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {
+        if (ix > 0x7f800000)
+            return x + x;
+        return hx > 0 ? 1.5707962513e+00f + 7.5497894159e-08f : -1.5707962513e+00f - 7.5497894159e-08f;
+    }
+    if (ix < 0x3ee00000) {
+        if (ix < 0x31000000)
+            return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) {
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else if (ix < 0x401c0000) {
+            id = 2;
+            x = (x - 1.5f) / (1.0f + 1.5f * x);
+        } else {
+            id = 3;
+            x = -1.0f / x;
+        }
+    }
+    float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f + w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    if (id < 0)
+        return x - x * (s1 + s2);
+    const float hi = id == 0 ? 4.6364760399e-01f : id == 1 ? 7.8539812565e-01f : id == 2 ? 9.8279368877e-01f : 1.5707962513e+00f;
+    const float lo = id == 0 ? 5.0121582440e-09f : id == 1 ? 3.7748947079e-08f : id == 2 ? 3.4473217170e-08f : 7.5497894159e-08f;
+    z = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -z : z;
+}
+RTX_DEV float hostAtan2f(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = __float_as_int(x), ix = hx & 0x7fffffff, hy = __float_as_int(y), iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000)
+        return x + y;
+    if (hx == 0x3f800000)
+        return hostAtanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2); // 2 * sign(x) + sign(y)
+    if (iy == 0)
+        return m < 2 ? y : m == 2 ? pi + tiny : -pi - tiny;
+    if (ix == 0)
+        return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000)
+            return m == 0 ? pi_o_4 + tiny : m == 1 ? -pi_o_4 - tiny : m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny;
+        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000)
+        return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = (iy - ix) >> 23;
+    float z;
+    if (k > 60)
+        z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60)
+        z = 0.0f;
+    else
+        z = hostAtanf(fabsf(y / x));
+    return m == 0 ? z : m == 1 ? __uint_as_float(__float_as_uint(z) ^ 0x80000000u) : m == 2 ? pi - (z - pi_lo) : (z - pi_lo) - pi;
+}
+RTX_DEV float hostAcosf(float x)
+{
+    const float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f, pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f;
+    const float qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const int32_t hx = __float_as_int(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000)
+        return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000)
+        return (x - x) / (x - x); // (outside [-1, 1], or a NaN: NaN)
+    const bool small = ix < 0x3f000000;
+    if (small && ix <= 0x23000000)
+        return pio2_hi + pio2_lo;
+    const float z = small ? x * x : hx < 0 ? (1.0f + x) * 0.5f : (1.0f - x) * 0.5f;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    if (small)
+        return pio2_hi - (x - (pio2_lo - x * r));
+    const float s = __builtin_sqrtf(z);
+    if (hx < 0) {
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float w = r * s + c;
+    return 2.0f * (df + w);
+}
+// (k_tanf.c: the tangent, or with iy = -1 the negative cotangent, of x + y on [-pi / 4, pi / 4])
+RTX_DEV float hostKernelTanf(float x, float y, int iy)
+{
+    const float pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;
+    const int32_t hx = __float_as_int(x), ix = hx & 0x7fffffff;
+    if (ix < 0x39000000 && int(x) == 0) {
+        if ((ix | (iy + 1)) == 0)
+            return 1.0f / fabsf(x);
+        return iy == 1 ? x : -1.0f / x;
+    }
+    const bool big = ix >= 0x3f2ca140;
+    if (big) {
+        if (hx < 0) {
+            x = -x;
+            y = -y;
+        }
+        const float z = pio4 - x, w = pio4lo - y;
+        x = z + w;
+        y = 0.0f;
+        if (fabsf(x) < 0x1p-13f)
+            return float((1 - ((hx >> 30) & 2)) * iy) * (1.0f - float(2 * iy) * x);
+    }
+    float z = x * x;
+    float w = z * z;
+    float r = 1.3333334029e-01f + w * (2.1869488060e-02f + w * (3.5920790397e-03f + w * (5.8804126456e-04f + w * (7.8179444245e-05f + w * -1.8558637748e-05f))));
+    float v = z * (5.3968254477e-02f + w * (8.8632395491e-03f + w * (1.4562094584e-03f + w * (2.4646313977e-04f + w * (7.1407252108e-05f + w * 2.5907305826e-05f)))));
+    float s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += 3.3333334327e-01f * s;
+    w = x + r;
+    if (big) {
+        v = float(iy);
+        return float(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1)
+        return w;
+    z = __uint_as_float(__float_as_uint(w) & 0xfffff000u);
+    v = r - (z - x);
+    const float a = -1.0f / w;
+    const float t = __uint_as_float(__float_as_uint(a) & 0xfffff000u);
+    s = 1.0f + t * z;
+    return t + a * (s + t * v);
+}
+RTX_DEV float hostTanf(float x)
+{
+    const int32_t ix = __float_as_int(x) & 0x7fffffff;
+    if (ix <= 0x3f490fda)
+        return hostKernelTanf(x, 0.0f, 1);
+    if (HostTrig::top12(x) >= HostTrig::top12(120.0f))
+        return tanf(x);
+    double dx = double(x);
+    const double r = dx * HostTrig::hpiInv;
+    const int n = (int32_t(r) + 0x800000) >> 24;
+    dx = dx - double(n) * HostTrig::hpi; // (this file of the library is built without fused multiply-add)
+    const float head = float(dx), tail = float(dx - double(head));
+    return hostKernelTanf(head, tail, 1 - ((n & 1) << 1));
+}
+
 // src/environment_mapping.cpp:167-207; the uv arithmetic is double there
 RTX_DEV V3 envColor(const DScene& sc, const rtx_features& f, V3 d)
 {
@@ -1081,13 +1315,13 @@ RTX_DEV V3 envColor(const DScene& sc, const rtx_features& f, V3 d)
         return bg;
     const rtx_texture& tx = sc.textures[sc.env.texture];
     const double kPi = 3.14159265358979323846;
-    const float x = float(double(atan2f(d.z, d.x)) / (2 * kPi) + 0.5);
+    const float x = float(double(hostAtan2f(d.z, d.x)) / (2 * kPi) + 0.5);
     const float cosUp = dot(normalize(d), mk(0.f, 1.f, 0.f));
     float y;
     if (sc.env.mapping == RTX_ENV_SPHERICAL)
-        y = float(-(kPi / double(sc.env.vfov_radians)) * (double(acosf(cosUp)) / kPi - 0.5) + 0.5);
+        y = float(-(kPi / double(sc.env.vfov_radians)) * (double(hostAcosf(cosUp)) / kPi - 0.5) + 0.5);
     else
-        y = float(0.5 / double(tanf(0.5f * sc.env.vfov_radians)) / double(tanf(acosf(cosUp))) + 0.5);
+        y = float(0.5 / double(hostTanf(0.5f * sc.env.vfov_radians)) / double(hostTanf(hostAcosf(cosUp))) + 0.5);
     if (fabs(double(y) - 0.5) > 0.5)
         return bg;
     if (f.enable_bilinear_texture_filtering)
@@ -1271,9 +1505,9 @@ RTX_DEV V3 envDirection(const DScene& sc, float cx, float cy)
     if (sc.env.mapping == RTX_ENV_SPHERICAL)
         pitch = float((0.5 - double(cy)) * double(sc.env.vfov_radians));
     else
-        pitch = float(atan(double(tanf(0.5f * sc.env.vfov_radians)) * (0.5 - double(cy)) / 0.5));
-    const float px = cosf(pitch), py = sinf(pitch);
-    return mk(px * cosf(azimuth), py, px * sinf(azimuth));
+        pitch = float(atan(double(hostTanf(0.5f * sc.env.vfov_radians)) * (0.5 - double(cy)) / 0.5));
+    const float px = hostCosf(pitch), py = hostSinf(pitch);
+    return mk(px * hostCosf(azimuth), py, px * hostSinf(azimuth));
 }
 
 // std::default_random_engine (minstd_rand0: x <- 16807 x mod 2^31-1, seed 1) as
@@ -1317,71 +1551,6 @@ RTX_DEV V3 rotate(float qw, V3 qv, V3 v)
     const V3 uv = cross(qv, v);
     const V3 uuv = cross(qv, uv);
     return v + ((uv * qw) + uuv) * 2.0f;
-}
-// sinf / cosf with the host C library's results.  glm::quat(euler) calls std::sin / std::cos on
-// floats, which on the hosts this runs beside is glibc's sinf / cosf (2.35,
-// sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, sincosf_data.c: the algorithm of Arm's
-// optimized routines): the argument is reduced and a degree-7 / degree-8 polynomial evaluated in
-// double, the result rounded to float once.  Its error is below 0.6 ulp but it is not the
-// correctly rounded value, and the device library's sinf / cosf round differently in about one
-// argument in ten: a motion-blur sample's camera then differs in its last bit and its ray
-// crosses a silhouette on the other side.  Restated here with the same coefficients and, as in
-// the variant glibc runs on a CPU with fused multiply-add, one rounding per multiply-add:
-// 749 million arguments below 120 in magnitude (every third float) give the host's bits without
-// exception.  Arguments of 120 and beyond (nineteen turns of the camera) take the device
-// library's routine.
-struct HostTrig {
-    static constexpr double hpiInv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
-    static constexpr double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
-    static constexpr double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
-    static __device__ __forceinline__ uint32_t top12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
-    // sine (n even) or cosine (n odd) of the reduced argument; `flip`: the cosine's sign in the
-    // second half of the turn (glibc keeps a second table with the cosine's coefficients negated)
-    static __device__ __forceinline__ float poly(double x, double x2, int n, bool flip)
-    {
-        if ((n & 1) == 0) {
-            const double x3 = x * x2;
-            const double t = __builtin_fma(x2, s3, s2);
-            const double x7 = x3 * x2;
-            const double s = __builtin_fma(x3, s1, x);
-            return float(__builtin_fma(x7, t, s));
-        }
-        const double sg = flip ? -1.0 : 1.0; // (an exact negation of every coefficient, hence of every intermediate)
-        const double x4 = x2 * x2;
-        const double h = __builtin_fma(x2, sg * c4, sg * c3);
-        const double l = __builtin_fma(x2, sg * c1, sg * c0);
-        const double x6 = x4 * x2;
-        const double c = __builtin_fma(x4, sg * c2, l);
-        return float(__builtin_fma(x6, h, c));
-    }
-    // quarter turns in y, and what is left of it (|y| < 120: the product fits the conversion)
-    static __device__ __forceinline__ double reduce(double x, int& n)
-    {
-        const double r = x * hpiInv;
-        n = (int32_t(r) + 0x800000) >> 24;
-        return __builtin_fma(-double(n), hpi, x);
-    }
-    static __device__ __forceinline__ float sinCos(float y, int cosine)
-    {
-        double x = double(y);
-        if (top12(y) < top12(0x1.921FB6p-1f)) { // |y| below pi / 4
-            if (top12(y) < top12(0x1p-12f))
-                return cosine ? 1.0f : y;
-            return poly(x, x * x, cosine, false);
-        }
-        int n;
-        x = reduce(x, n);
-        const double sign = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
-        return poly(x * sign, x * x, n ^ cosine, (n & 2) != 0);
-    }
-};
-RTX_DEV float hostSinf(float y)
-{
-    return HostTrig::top12(y) < HostTrig::top12(120.0f) ? HostTrig::sinCos(y, 0) : sinf(y);
-}
-RTX_DEV float hostCosf(float y)
-{
-    return HostTrig::top12(y) < HostTrig::top12(120.0f) ? HostTrig::sinCos(y, 1) : cosf(y);
 }
 // glm::quat(euler), glm/detail/type_quat.inl:208-217 (on the device: used only by
 // the motion-blur driver, whose per-sample cameras cannot be prepared on the host)

@@ -3547,13 +3547,16 @@ int uploadShading(rtx_scene* s, const rtx_scene_desc* d)
 }
 
 // Keeps one wave busy for `ticks` of the 100 MHz wall clock (streamsOverlap).
-// the device's restatement of the host library's sinf / cosf, for rtx_selfcheck_trig
-__global__ void __launch_bounds__(256) trigKernel(const float* x, uint32_t n, float* sinOut, float* cosOut)
+// the device's restatements of the host library's routines, for rtx_selfcheck_trig
+__global__ void __launch_bounds__(256) trigKernel(const float* x, const float* y, uint32_t n, float* out)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) {
-        sinOut[i] = rtxd::hostSinf(x[i]);
-        cosOut[i] = rtxd::hostCosf(x[i]);
+        out[i] = rtxd::hostSinf(x[i]);
+        out[size_t(n) + i] = rtxd::hostCosf(x[i]);
+        out[2 * size_t(n) + i] = rtxd::hostTanf(x[i]);
+        out[3 * size_t(n) + i] = rtxd::hostAcosf(x[i]);
+        out[4 * size_t(n) + i] = rtxd::hostAtan2f(y[i], x[i]);
     }
 }
 
@@ -4584,18 +4587,18 @@ int rtx_set_stream(void* hipStream)
     return RTX_OK;
 }
 
-int rtx_selfcheck_trig(const float* x, size_t n, float* sinOut, float* cosOut)
+int rtx_selfcheck_trig(const float* x, const float* y, size_t n, float* out)
 {
     if (int rc = checkCtx(nullptr))
         return rc;
-    if (n > (size_t(1) << 30) || (n && (!x || !sinOut || !cosOut))) {
-        setErr("rtx_selfcheck_trig: %zu arguments (at most 2^30), or a null array", n);
+    if (n > (size_t(1) << 28) || (n && (!x || !y || !out))) {
+        setErr("rtx_selfcheck_trig: %zu arguments (at most 2^28), or a null array", n);
         return RTX_ERR_INVALID;
     }
     DeviceCtx* c = g_ctx;
     std::lock_guard<std::mutex> launchLock(c->launch);
     if (n) {
-        hipLaunchKernelGGL(trigKernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, c->stream, x, uint32_t(n), sinOut, cosOut);
+        hipLaunchKernelGGL(trigKernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, c->stream, x, y, uint32_t(n), out);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -50,7 +50,7 @@ def hip_lib():
         lib.rtx_set_stream.argtypes = [vp]
         lib.rtx_select_slot.argtypes = [C.c_int]
         lib.rtx_streams_overlap.argtypes = [vp, vp]
-        lib.rtx_selfcheck_trig.argtypes = [vp, C.c_size_t, vp, vp]
+        lib.rtx_selfcheck_trig.argtypes = [vp, vp, C.c_size_t, vp]
         _hip = lib
     return _hip
 

@@ -123,12 +123,14 @@ def test_random_soups_under_every_driver(gpu_device, seed):
     orc.close()
 
 
-def test_device_sine_and_cosine_are_the_host_librarys(gpu_device):
-    """The motion-blur driver's per-sample cameras come from glm::quat(euler) (src/render.cpp:203-247),
-    that is from the host C library's sinf / cosf: the device's restatement of that routine must
-    give its bits.  Checked on half-angles a camera can have (every float pattern in steps over
-    +-2 pi, densely around the multiples of pi / 4 where the routine changes branch) and up to the
-    routine's range of +-120."""
+def test_device_trigonometry_is_the_host_librarys(gpu_device):
+    """Where the path turns an angle into a discrete outcome it must use the host C library's
+    results, as the reference does: the motion-blur driver's per-sample cameras (glm::quat(euler),
+    src/render.cpp:203-247: sinf / cosf) and the environment map's texture coordinates
+    (src/environment_mapping.cpp:130-207: atan2f, acosf, tanf).  The device's restatements of those
+    routines must give libm's bits: on half-angles a camera can have (float patterns in steps over
+    +-2 pi, densely around the multiples of pi / 4 where the routines change branch), up to the
+    sine's fast range of +-120, on cosines in [-1, 1] and on direction components."""
     import ctypes as C
     import ctypes.util
     import torch
@@ -136,22 +138,47 @@ def test_device_sine_and_cosine_are_the_host_librarys(gpu_device):
     lib = engine.hip_lib()
     assert lib.rtx_init(0) == 0
     libm = C.CDLL(ctypes.util.find_library("m"))
-    libm.sinf.restype = libm.cosf.restype = C.c_float
-    libm.sinf.argtypes = libm.cosf.argtypes = [C.c_float]
+    for fn in (libm.sinf, libm.cosf, libm.tanf, libm.acosf):
+        fn.restype, fn.argtypes = C.c_float, [C.c_float]
+    libm.atan2f.restype, libm.atan2f.argtypes = C.c_float, [C.c_float, C.c_float]
     rng = np.random.default_rng(11)
     top = np.float32(2 * np.pi).view(np.uint32)
-    bits = np.arange(0, int(top), 9973, dtype=np.uint32)                      # positive floats up to 2 pi
-    near = np.concatenate([(np.float32(k * np.pi / 4).view(np.uint32) + np.arange(-300, 301)).astype(np.uint32) for k in range(1, 40)])
-    x = np.concatenate([bits.view(np.float32), near.view(np.float32), (rng.random(60000) * 120).astype(np.float32),
+    bits = np.arange(0, int(top), 19997, dtype=np.uint32)                     # positive floats up to 2 pi
+    near = np.concatenate([(np.float32(k * np.pi / 4).view(np.uint32) + np.arange(-150, 151)).astype(np.uint32) for k in range(1, 40)])
+    unit = np.concatenate([rng.random(30000) * 2 - 1, 1 - rng.random(3000) * 1e-3, rng.random(3000) * 1e-3 - 1, [1.0, -1.0, 0.5, -0.5, 1.0000001]])
+    x = np.concatenate([bits.view(np.float32), near.view(np.float32), (rng.random(30000) * 120).astype(np.float32), unit.astype(np.float32),
                         np.array([0.0, 1e-30, 2.0 ** -12, np.nextafter(np.float32(2.0 ** -12), np.float32(0)), 119.99999], np.float32)])
     x = np.concatenate([x, -x])
-    assert np.abs(x).max() < 120 and len(x) > 250000
-    dx = torch.from_numpy(x).cuda()
-    ds, dc = torch.empty_like(dx), torch.empty_like(dx)
-    assert lib.rtx_selfcheck_trig(C.c_void_p(dx.data_ptr()), C.c_size_t(len(x)), C.c_void_p(ds.data_ptr()), C.c_void_p(dc.data_ptr())) == 0, lib.rtx_last_error()
-    want_s = np.array([libm.sinf(float(v)) for v in x], np.float32)
-    want_c = np.array([libm.cosf(float(v)) for v in x], np.float32)
-    bad_s = np.flatnonzero(ds.cpu().numpy().view(np.uint32) != want_s.view(np.uint32))
-    bad_c = np.flatnonzero(dc.cpu().numpy().view(np.uint32) != want_c.view(np.uint32))
-    assert len(bad_s) == 0, f"sinf differs for {len(bad_s)} arguments, first {x[bad_s[:4]]}"
-    assert len(bad_c) == 0, f"cosf differs for {len(bad_c)} arguments, first {x[bad_c[:4]]}"
+    y = (rng.normal(size=len(x)) * np.abs(x) * 10.0 ** rng.integers(-3, 4, len(x))).astype(np.float32)
+    y[::17] = 0.0
+    y[5::19] = x[5::19]
+    n = len(x)
+    assert np.abs(x).max() < 120 and n > 150000
+    dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    out = torch.empty(5 * n, dtype=torch.float32, device="cuda")
+    assert lib.rtx_selfcheck_trig(C.c_void_p(dx.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_size_t(n), C.c_void_p(out.data_ptr())) == 0, lib.rtx_last_error()
+    got = out.cpu().numpy().reshape(5, n)
+    want = np.array([[libm.sinf(float(v)) for v in x], [libm.cosf(float(v)) for v in x], [libm.tanf(float(v)) for v in x],
+                     [libm.acosf(float(v)) for v in x], [libm.atan2f(float(b), float(a)) for a, b in zip(x, y)]], np.float32)
+    for row, name in enumerate(("sinf", "cosf", "tanf", "acosf", "atan2f")):
+        g, w = got[row], want[row]
+        bad = np.flatnonzero((g.view(np.uint32) != w.view(np.uint32)) & ~(np.isnan(g) & np.isnan(w)))
+        assert len(bad) == 0, f"{name} differs for {len(bad)} arguments, first x = {x[bad[:4]]}, y = {y[bad[:4]]}"
+
+
+def test_nearest_texel_of_a_large_environment_map(gpu_device):
+    """Environment lookups without filtering in a 4096 x 2048 map of random texels: the frame must be
+    the oracle's in every pixel, which it only is when the texture coordinates have the reference's
+    bits (one lookup in ten thousand lands on a neighbouring texel otherwise)."""
+    rng = np.random.default_rng(5)
+    for mapping, vfov in ((abi.ENV_SPHERICAL, 180.0), (abi.ENV_CYLINDRICAL, 120.0)):
+        scene = cases.load_scene("triangle")
+        scene.set_envmap((np.floor(rng.random((2048, 4096, 3)) * 256) / 255.0).astype(np.float32), mapping, vfov, (0.5, 0.5, 0.5))
+        f = abi.features(**dict(cases.BASE, environment_mapping=1))
+        gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+        for rot in ((20, 20, 0), (-40, 130, 0), (75, 250, 0)):
+            cam = make_camera(rotation_degrees=rot)
+            rp = make_params(512, 288)
+            assert_images_close(gpu.render(cam, f, rp), orc.render(cam, f, rp), f"mapping {mapping}, camera {rot}")
+        gpu.close()
+        orc.close()
