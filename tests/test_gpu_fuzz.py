@@ -123,6 +123,36 @@ def test_random_soups_under_every_driver(gpu_device, seed):
     orc.close()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTX_FUZZ_SEEDS", "24"))))
+def test_random_soups_with_textures_and_an_environment_map(gpu_device, seed):
+    """The soups again with a random texture per mesh (every filter) in front of a random
+    environment map that mirrors reflect and that lights the scene."""
+    scene, rng = random_scene(seed)
+    for m in scene.meshes:
+        # (square: the reference's chain of smaller images, src/main.cpp:745-771, reads outside the
+        # image once one side of it reaches 1 before the other, and leaves a level of width 0)
+        side = [4, 64, 256, 512][int(rng.integers(0, 4))]
+        m.texture = (np.floor(rng.random((side, side, 3)) * 256) / 255.0).astype(np.float32)
+        m.vertices[:, 6:8] = (rng.random((len(m.vertices), 2)) * 3 - 1).astype(np.float32) if rng.random() < 0.3 else m.vertices[:, 6:8]
+    mapping = abi.ENV_SPHERICAL if rng.random() < 0.5 else abi.ENV_CYLINDRICAL
+    scene.set_envmap((np.floor(rng.random((256, 512, 3)) * 256) / 255.0).astype(np.float32), mapping, 180.0 if mapping == abi.ENV_SPHERICAL else 60.0 + 90.0 * rng.random(),
+                     tuple(rng.random(3)))
+    outside, inside = random_camera(rng), random_camera(rng, distance=0.15)
+    for filters in (dict(), dict(bilinear_texture_filtering=1), dict(bilinear_texture_filtering=1, mipmap_texture_filtering=1)):
+        f = abi.features(**dict(cases.BASE, recursive=1, texture_mapping=1, environment_mapping=1, **filters))
+        gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+        check_frame(gpu, orc, outside, f, make_params(64, 36), f"soup {seed}, textures {filters}")
+        check_frame(gpu, orc, inside, f, make_params(48, 27, driver=abi.DRIVER_MRAYS, samples=2), f"soup {seed} from inside, textures {filters}")
+        gpu.close()
+        orc.close()
+    # the environment as a light (importance-sampled), with and without the point lights' own shadows
+    f = abi.features(**dict(cases.BASE, soft_shadow=1, texture_mapping=1, environment_mapping=1))
+    gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+    check_frame(gpu, orc, outside, f, make_params(40, 22, shadow_samples=7), f"soup {seed}, environment light")
+    gpu.close()
+    orc.close()
+
+
 def test_device_trigonometry_is_the_host_librarys(gpu_device):
     """Where the path turns an angle into a discrete outcome it must use the host C library's
     results, as the reference does: the motion-blur driver's per-sample cameras (glm::quat(euler),
