@@ -112,6 +112,20 @@ def test_random_soups_under_every_driver(gpu_device, seed):
         check_frame(gpu, orc, outside, f, make_params(40, 22), f"soup {seed}, {feat}")
         gpu.close()
         orc.close()
+    # the tree built on the device (another tree: same hits), and a frame large enough for the
+    # scheduler's block classes, culling and ordering to matter
+    dev, orc = GpuEngine(scene, base, device_build=True), OracleEngine(scene, base)
+    got, want = dev.intersect(rays, base), orc.intersect(rays, base)
+    hit = want["hit"] != 0
+    assert np.array_equal(got["hit"] != 0, hit) and np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), f"soup {seed}, device-built tree"
+    check_frame(dev, orc, outside, mirror, make_params(56, 32), f"soup {seed}, device-built tree")
+    dev.close()
+    gpu = GpuEngine(scene, base)
+    big = make_params(400, 224, driver=abi.DRIVER_MRAYS, samples=4)
+    check_frame(gpu, orc, outside2, base, big, f"soup {seed}, 400x224x4")
+    check_frame(gpu, orc, outside2, base, big, f"soup {seed}, 400x224x4 again (blocks in the measured order)")
+    gpu.close()
+    orc.close()
     # area lights: a segment and a parallelogram, glossy reflections to depth 2
     soft = abi.features(**dict(cases.BASE, hard_shadow=0, soft_shadow=1, recursive=1, glossy_reflection=1))
     scene.lights = [abi.segment_light((-0.5, 1.0, 0.2), (0.5, 1.1, -0.2), (1, 0.8, 0.6), (0.6, 0.8, 1)),
@@ -119,6 +133,40 @@ def test_random_soups_under_every_driver(gpu_device, seed):
     gpu, orc = GpuEngine(scene, soft), OracleEngine(scene, soft)
     check_frame(gpu, orc, outside, soft, make_params(40, 22, shadow_samples=6, glossy_rays=2, ray_depth=2), f"soup {seed}, area lights + glossy")
     check_frame(gpu, orc, inside, soft, make_params(32, 18, driver=abi.DRIVER_MRAYS, samples=2, shadow_samples=3, glossy_rays=2, ray_depth=1), f"soup {seed}, area lights from inside")
+    gpu.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("scale", [0.004, 40.0, 3000.0])
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTX_FUZZ_SEEDS", "8"))))
+def test_random_soups_at_other_scales(gpu_device, seed, scale):
+    """The soups shrunk and blown up, camera and lights with them: the shadow queries' shortcuts
+    hold only within stated coordinate ranges and must step aside outside them; the 1e-3 and 1e-5
+    offsets of the reference's shadow test and bounce rays mean something else at each scale."""
+    scene, rng = random_scene(seed)
+    for m in scene.meshes:
+        m.vertices[:, 0:3] *= np.float32(scale)
+    scene.spheres = [(c * np.float32(scale), r * scale, mat) for c, r, mat in scene.spheres]
+    lights = []
+    for l in scene.lights:
+        lights.append(abi.point_light(tuple(float(np.float32(v) * np.float32(scale)) for v in l.p[0]), tuple(l.c[0])))
+    scene.lights = lights
+    cam = random_camera(rng)
+    cam.distance = float(np.float32(cam.distance) * np.float32(scale))
+    cam.look_at[:] = [float(np.float32(v) * np.float32(scale)) for v in cam.look_at]
+    mirror = abi.features(**dict(cases.BASE, recursive=1))
+    gpu, orc = GpuEngine(scene, mirror), OracleEngine(scene, mirror)
+    check_frame(gpu, orc, cam, mirror, make_params(64, 36, ray_depth=2), f"soup {seed} x {scale}")
+    check_frame(gpu, orc, cam, mirror, make_params(48, 27, driver=abi.DRIVER_MRAYS, samples=4), f"soup {seed} x {scale}, 4 samples")
+    check_frame(gpu, orc, cam, mirror, make_params(20, 12), f"soup {seed} x {scale}, 20x12")
+    gpu.close()
+    orc.close()
+    soft = abi.features(**dict(cases.BASE, hard_shadow=0, soft_shadow=1, recursive=1, glossy_reflection=1))
+    e = np.float32(scale)
+    scene.lights = [abi.parallelogram_light((0.9 * e, -0.2 * e, -0.2 * e), (0, 0.4 * e, 0), (0, 0, 0.4 * e), (1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1)),
+                    abi.segment_light((-0.5 * e, 1.0 * e, 0.2 * e), (0.5 * e, 1.1 * e, -0.2 * e), (1, 0.8, 0.6), (0.6, 0.8, 1))]
+    gpu, orc = GpuEngine(scene, soft), OracleEngine(scene, soft)
+    check_frame(gpu, orc, cam, soft, make_params(40, 22, shadow_samples=5, glossy_rays=2, ray_depth=2), f"soup {seed} x {scale}, area lights + glossy")
     gpu.close()
     orc.close()
 
