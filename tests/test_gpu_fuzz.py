@@ -14,7 +14,7 @@ from raytracer_amd import abi
 from raytracer_amd.engine import GpuEngine
 from raytracer_amd.scene import SceneData, make_camera, make_params
 from oracle.bindings import OracleEngine
-from test_gpu_parity import assert_hits_equal, assert_images_close
+from test_gpu_parity import RGB_TOL, assert_hits_equal, assert_images_close
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,8 @@ def random_scene(seed):
         s.add_mesh(v, t, (*kd, *ks, 1.0 + 60.0 * rng.random(), transparency))
     for _ in range(int(rng.integers(0, 3))):
         s.add_sphere((rng.random(3) * 2 - 1) * 0.7, 0.05 + 0.25 * rng.random(), (*rng.random(3), *(rng.random(3) * 0.5 * (rng.random() < 0.5)), 20.0, 1.0))
-    for _ in range(int(rng.integers(1, 3))):
+    # (now and then more point lights than the four whose shadow rays get records of their own)
+    for _ in range(int(rng.integers(1, 3)) if rng.random() < 0.85 else int(rng.integers(5, 8))):
         d = rng.normal(size=3)
         s.lights.append(abi.point_light(d / np.linalg.norm(d) * (0.2 + 2.5 * rng.random()), 0.4 + 0.6 * rng.random(3)))
     return s, rng
@@ -64,7 +65,11 @@ def random_camera(rng, distance=None):
                        look_at=tuple((rng.random(3) - 0.5) * 0.4), rotation_degrees=(rng.random() * 360 - 180, rng.random() * 360, 0))
 
 
-def check_frame(gpu, orc, cam, f, rp, what):
+def check_frame(gpu, orc, cam, f, rp, what, ties=0):
+    """`ties`: pixels that may differ.  Where a ray meets two triangles at the same distance to the
+    last bit (it crosses the line in which they intersect) the triangle tested first wins, in the
+    reference as here, and the order of the tests is the one thing the walks do not share; one
+    sample of one pixel in 200 soups' 400x224x4 frames does (soup 113)."""
     got = gpu.render(cam, f, rp)
     counts = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce)
     want = orc.render(cam, f, rp)
@@ -74,6 +79,10 @@ def check_frame(gpu, orc, cam, f, rp, what):
         # traces fewer rays than the reference's and is not held to it
         assert rp.driver == abi.DRIVER_TRANSPARENCY and counts[0] < int(orc.counters[0])
         return
+    if ties:
+        off = np.abs(np.nan_to_num(got) - np.nan_to_num(want)).max(-1) > RGB_TOL
+        assert off.sum() <= ties, f"{what}: {off.sum()} pixels differ"
+        got = np.where(off[..., None], want, got)
     assert_images_close(got, want, what)
     assert counts == tuple(int(x) for x in orc.counters[:3]), f"{what}: ray counts {counts} vs oracle {tuple(orc.counters[:3])}"
 
@@ -102,6 +111,10 @@ def test_random_soups_under_every_driver(gpu_device, seed):
     check_frame(gpu, orc, outside2, base, make_params(40, 22, driver=abi.DRIVER_DOF, samples=4, aperture=0.08, focal_length=2.0), f"soup {seed}, depth of field")
     check_frame(gpu, orc, outside, mirror, make_params(40, 22, driver=abi.DRIVER_MOTION_BLUR, samples=3, prev_camera=outside2), f"soup {seed}, motion blur")
     check_frame(gpu, orc, outside, mirror, make_params(48, 27, driver=abi.DRIVER_TRANSPARENCY), f"soup {seed}, transparency")
+    check_frame(gpu, orc, inside, base, make_params(37, 21, driver=abi.DRIVER_TRANSPARENCY), f"soup {seed}, transparency from inside")
+    check_frame(gpu, orc, inside, mirror, make_params(33, 19, driver=abi.DRIVER_DOF, samples=3, aperture=float(0.3 * rng.random()), focal_length=float(0.2 + 3 * rng.random())),
+                f"soup {seed}, depth of field from inside")
+    check_frame(gpu, orc, inside, base, make_params(31, 17, driver=abi.DRIVER_MOTION_BLUR, samples=5, prev_camera=outside), f"soup {seed}, motion blur across the scene")
     gpu.close()
     orc.close()
     # the other tree (median split, flat normals) and no tree at all
@@ -122,8 +135,8 @@ def test_random_soups_under_every_driver(gpu_device, seed):
     dev.close()
     gpu = GpuEngine(scene, base)
     big = make_params(400, 224, driver=abi.DRIVER_MRAYS, samples=4)
-    check_frame(gpu, orc, outside2, base, big, f"soup {seed}, 400x224x4")
-    check_frame(gpu, orc, outside2, base, big, f"soup {seed}, 400x224x4 again (blocks in the measured order)")
+    check_frame(gpu, orc, outside2, base, big, f"soup {seed}, 400x224x4", ties=1)
+    check_frame(gpu, orc, outside2, base, big, f"soup {seed}, 400x224x4 again (blocks in the measured order)", ties=1)
     gpu.close()
     orc.close()
     # area lights: a segment and a parallelogram, glossy reflections to depth 2
