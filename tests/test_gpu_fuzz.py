@@ -214,6 +214,57 @@ def test_random_soups_with_textures_and_an_environment_map(gpu_device, seed):
     orc.close()
 
 
+def test_scenes_at_the_edge_of_being_scenes(gpu_device):
+    """Nothing at all, spheres without a triangle, triangles without a light, a lone zero-area
+    triangle, a single triangle seen edge-on: under the plain, multi-sample and transparency
+    drivers, with mirrors, on both trees and without a tree."""
+    def spheres_only():
+        s = SceneData()
+        s.add_sphere((0.1, 0.0, 0.2), 0.4, (0.8, 0.3, 0.2, 0.5, 0.5, 0.5, 10.0, 1.0))
+        s.add_sphere((-0.5, 0.2, -0.1), 0.25, (0.2, 0.8, 0.3, 0.0, 0.0, 0.0, 1.0, 1.0))
+        s.lights.append(abi.point_light((1.0, 2.0, 1.5)))
+        return s
+
+    def unlit():
+        s, _ = random_scene(3)
+        s.lights = []
+        return s
+
+    def one_triangle(corners):
+        s = SceneData()
+        v = np.zeros((3, 8), np.float32)
+        v[:, 0:3] = corners
+        v[:, 3:6] = (0, 0, 1)
+        s.add_mesh(v, [[0, 1, 2]], (0.7, 0.7, 0.2, 0.3, 0.3, 0.3, 5.0, 1.0))
+        s.lights.append(abi.point_light((0.5, 1.0, 2.0)))
+        return s
+
+    empty = SceneData()
+    empty.lights.append(abi.point_light((0.0, 1.0, 0.0)))
+    cam = make_camera()
+    edge_on = make_camera(rotation_degrees=(0, 90, 0))
+    scenes = (("empty", empty, cam), ("nothing, not even a light", SceneData(), cam), ("spheres only", spheres_only(), cam), ("no lights", unlit(), cam),
+              ("zero-area triangle", one_triangle([(0, 0, 0), (0.5, 0.5, 0), (0.5, 0.5, 0)]), cam),
+              ("a point for a triangle", one_triangle([(0.1, 0.1, 0.1)] * 3), cam),
+              ("triangle edge-on", one_triangle([(-0.5, -0.5, 0), (0.5, -0.5, 0), (0, 0.5, 0)]), edge_on))
+    for name, scene, camera in scenes:
+        for feat in (dict(cases.BASE, recursive=1), dict(shading=1, hard_shadow=1, recursive=1, accel_structure=1), dict(shading=1, hard_shadow=1, normal_interp=1)):
+            f = abi.features(**feat)
+            gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+            for rp in (make_params(40, 24), make_params(33, 17, driver=abi.DRIVER_MRAYS, samples=3), make_params(24, 24, driver=abi.DRIVER_TRANSPARENCY)):
+                check_frame(gpu, orc, camera, f, rp, f"{name}, {feat}, driver {rp.driver}")
+            rays = cases.ray_batch(scene, 1, n_random=300, grid=12)
+            assert_hits_equal(gpu.intersect(rays, f), orc.intersect(rays, f), f"{name}, {feat}: rays")
+            gpu.close()
+            orc.close()
+        if scene.n_triangles:
+            f = abi.features(**cases.BASE)
+            dev, orc = GpuEngine(scene, f, device_build=True), OracleEngine(scene, f)
+            check_frame(dev, orc, camera, f, make_params(40, 24), f"{name}, device-built tree")
+            dev.close()
+            orc.close()
+
+
 def test_device_trigonometry_is_the_host_librarys(gpu_device):
     """Where the path turns an angle into a discrete outcome it must use the host C library's
     results, as the reference does: the motion-blur driver's per-sample cameras (glm::quat(euler),
