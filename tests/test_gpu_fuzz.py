@@ -125,6 +125,15 @@ def test_random_soups_under_every_driver(gpu_device, seed):
         check_frame(gpu, orc, outside, f, make_params(40, 22), f"soup {seed}, {feat}")
         gpu.close()
         orc.close()
+    # getFinalColor on rays that are no camera's: started inside and outside the soup, some along
+    # an axis, some with a search limit in front of the geometry
+    gpu, orc = GpuEngine(scene, mirror), OracleEngine(scene, mirror)
+    loose = rays[-1200:]
+    got, want = gpu.final_color(loose, mirror, ray_depth=2), orc.final_color(loose, mirror, make_params(1, 1, ray_depth=2))
+    assert_images_close(got, want, f"soup {seed}, getFinalColor on loose rays")
+    assert (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce) == tuple(int(x) for x in orc.counters[:3])
+    gpu.close()
+    orc.close()
     # the tree built on the device (another tree: same hits), and a frame large enough for the
     # scheduler's block classes, culling and ordering to matter
     dev, orc = GpuEngine(scene, base, device_build=True), OracleEngine(scene, base)
@@ -146,6 +155,14 @@ def test_random_soups_under_every_driver(gpu_device, seed):
     gpu, orc = GpuEngine(scene, soft), OracleEngine(scene, soft)
     check_frame(gpu, orc, outside, soft, make_params(40, 22, shadow_samples=6, glossy_rays=2, ray_depth=2), f"soup {seed}, area lights + glossy")
     check_frame(gpu, orc, inside, soft, make_params(32, 18, driver=abi.DRIVER_MRAYS, samples=2, shadow_samples=3, glossy_rays=2, ray_depth=1), f"soup {seed}, area lights from inside")
+    from raytracer_amd.engine import host_lib
+    host_lib().rtxh_set_sampling(4, 3, 7)
+    try:
+        got = gpu.final_color(loose[:400], soft, ray_depth=2)
+    finally:
+        host_lib().rtxh_set_sampling(50, 5, 1)
+    want = orc.final_color(loose[:400], soft, make_params(1, 1, ray_depth=2, shadow_samples=4, glossy_rays=3, seed=7))
+    assert_images_close(got, want, f"soup {seed}, getFinalColor on loose rays under area lights")
     gpu.close()
     orc.close()
 
