@@ -155,7 +155,17 @@ def test_random_soups_under_every_driver(gpu_device, seed):
     gpu, orc = GpuEngine(scene, soft), OracleEngine(scene, soft)
     check_frame(gpu, orc, outside, soft, make_params(40, 22, shadow_samples=6, glossy_rays=2, ray_depth=2), f"soup {seed}, area lights + glossy")
     check_frame(gpu, orc, inside, soft, make_params(32, 18, driver=abi.DRIVER_MRAYS, samples=2, shadow_samples=3, glossy_rays=2, ray_depth=1), f"soup {seed}, area lights from inside")
-    from raytracer_amd.engine import host_lib
+    # the frame in the interleaved tiles of two and of five ranks: together they are the frame
+    import ctypes as C
+    from raytracer_amd.engine import host_lib, _ptr
+    tiled = dict(width=53, height=31, shadow_samples=4, glossy_rays=2, ray_depth=2)
+    full = gpu.render(outside, soft, make_params(**tiled))
+    for world, tile in ((2, 8), (5, 16)):
+        acc = np.full((31, 53, 3), -7.0, np.float32)
+        for rank in range(world):
+            rp = make_params(**tiled, tile_size=tile, tile_rank=rank, tile_world=world)
+            assert host_lib().rtxh_render(C.c_void_p(gpu.b), C.byref(outside), C.byref(soft), C.byref(rp), _ptr(acc), C.byref(gpu.stats)) == 0
+        assert np.array_equal(acc.view(np.uint32), full.view(np.uint32)), f"soup {seed}: tiles of {world} ranks do not assemble the frame"
     host_lib().rtxh_set_sampling(4, 3, 7)
     try:
         got = gpu.final_color(loose[:400], soft, ray_depth=2)
