@@ -784,6 +784,29 @@ def test_dragon_standin_full_size_properties(gpu_device):
     gpu.close()
 
 
+def test_full_size_frames_are_the_same_by_both_walks(gpu_device, monkeypatch):
+    """BASELINE config 2 at its full 1920x1080x16, where the oracle is out of reach: the frame by
+    the wave-shared walk (four-wide nodes in mirrored octant copies, records relative to the
+    camera and the light) and the frame by the lane-by-lane walk (binary nodes, each ray alone;
+    held to the oracle ray by ray elsewhere) must be the same bits -- two traversals that share
+    only the triangle arithmetic.  33 M camera rays per view, head-on, close up and from behind."""
+    from raytracer_amd.scene import winding_dragon_scene
+    f = abi.features(**cases.BASE)
+    rp = make_params(1920, 1080, driver=abi.DRIVER_MRAYS, samples=16)
+    for name, scene, cam in (("dragon", dragon_scene(), make_camera()), ("dragon close up", dragon_scene(), make_camera(distance=1.2)),
+                             ("winding dragon from behind", winding_dragon_scene(), make_camera(rotation_degrees=(-30, 140, 0), distance=1.4))):
+        frames, counts = [], []
+        for walk in ("1", "0"):
+            monkeypatch.setenv("RTX_LEAN_WALK", walk)
+            gpu = GpuEngine(scene, f)
+            frames.append(gpu.render(cam, f, rp))
+            counts.append((gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.shaded_hits))
+            gpu.close()
+        assert counts[0] == counts[1] and counts[0][0] == 1920 * 1080 * 16, name
+        differ = int((frames[0].view(np.uint32) != frames[1].view(np.uint32)).any(-1).sum())
+        assert differ == 0, f"{name}: {differ} pixels differ between the walks"
+
+
 def test_winding_dragon_standin_against_the_oracle(gpu_device):
     """The harder stand-in (a body coiled through space, thin wing membranes, legs, spikes: rays
     cross it several times, many graze it): frames, ray counts and primary hits against the oracle,
