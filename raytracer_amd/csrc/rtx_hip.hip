@@ -3083,7 +3083,28 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // measured at 3840x2160: together wins up to ~0.3 triangles per pixel, 0.60 against 0.87 ms at
     // 0.04, and loses beyond, 1.41 against 1.26 ms at 1.2; RTX_LEAN_WALK=0/1 overrides)
     const bool sparse = double(scene->d.nTris) <= 0.3 * double(A.W) * double(A.H);
-    const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : driver != RTX_DRIVER_DOF && (A.lanesPerPixel >= 2 || sparse);
+    // (the motion-blur driver's samples of a pixel come from as many camera poses: a bundle only
+    // while the poses stay close.  How far they stray from the middle pose, in pixels at the
+    // distance of what the camera looks at -- measured, 7 samples: together wins below some 60-80
+    // pixels on 10 M triangles at 3840x2160 (5.3 against 7.8 ms at 8 pixels, 11.7 against 12.0 at
+    // 81) and loses beyond (35 against 18 ms at 116), and up to some 200 pixels where triangles
+    // are large on the screen (headline scene: 1.29 against 1.45 ms at 200))
+    double swayPixels = 0.0;
+    if (driver == RTX_DRIVER_MOTION_BLUR) {
+        double dl = 0.0, turn = 0.0;
+        for (int i = 0; i < 3; i++) {
+            const double dLook = double(cam->look_at[i]) - double(p->prev_camera.look_at[i]);
+            dl += dLook * dLook;
+            turn += 0.5 * std::fabs(double(cam->euler[i]) - double(p->prev_camera.euler[i]));
+        }
+        const double dDist = double(cam->distance) - double(p->prev_camera.distance), distMid = std::fabs(double(cam->distance) + 0.5 * dDist);
+        const double sway = 0.5 * std::sqrt(dl) + 0.5 * std::fabs(dDist) + (distMid + 0.5 * std::fabs(dDist)) * turn;
+        swayPixels = sway / (std::max(distMid, 1e-9) * std::max(double(cam->half_height), 1e-9)) * 0.5 * double(A.H);
+        if (!std::isfinite(swayPixels))
+            swayPixels = INFINITY;
+    }
+    const bool bundles = driver != RTX_DRIVER_DOF && (driver != RTX_DRIVER_MOTION_BLUR || swayPixels <= (sparse ? 256.0 : 64.0));
+    const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : bundles && (A.lanesPerPixel >= 2 || sparse);
     // (the motion-blur driver's lean kernels carry the per-sample camera's trigonometry: modes 6 / 7)
     const int mode = !full ? (driver == RTX_DRIVER_MOTION_BLUR ? (together ? 6 : 7) : (together ? 0 : 5)) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
     // Mode 8 = mode 0 with every ray of the frame read from an origin's frame: the camera rays
