@@ -9,18 +9,16 @@
 //
 //   * the visual-debug hooks of src/draw.h:18-28 as no-ops (they draw with
 //     OpenGL and return nothing, so they cannot influence any computed value);
-//   * Screen's framebuffer methods (src/screen.h:10-33) without the GL texture;
-//   * the Trackball methods the frame drivers call (trackball.h:14-59), written
-//     against the reference's own vendored glm so the quaternion arithmetic is
-//     glm's.  These are this harness's statement of
-//     framework/src/trackball.cpp:64-110, NOT reference code: primary-ray
-//     generation is therefore pinned by restatement only.
+//   * Screen's constructor (src/screen.cpp:16-30) without the GL texture;
+//   * Trackball's constructor (framework/src/trackball.cpp:23-50) without the Window.
+// The methods of the two classes that the frame drivers call -- Trackball::position /
+// generateRay, Screen::setPixel and their neighbours -- are NOT restated here: their lines
+// are extracted from the reference at build time (camera_screen_tu.cpp).
 #include "draw.h"
 #include "screen.h"
 #include <framework/trackball.h>
 #include <glm/gtc/quaternion.hpp>
 #include <cmath>
-#include <limits>
 
 bool enableDebugDraw = false;
 
@@ -42,19 +40,7 @@ Screen::Screen(const glm::ivec2& resolution, bool presentable)
 {
     (void)presentable;
 }
-void Screen::clear(const glm::vec3& color)
-{
-    for (auto& p : m_textureData)
-        p = color;
-}
-void Screen::setPixel(int x, int y, const glm::vec3& color)
-{
-    m_textureData[size_t(indexAt(x, y))] = color;
-}
-glm::ivec2 Screen::resolution() const { return m_resolution; }
-int Screen::indexAt(int x, int y) const { return (m_resolution.y - 1 - y) * m_resolution.x + x; }
-const std::vector<glm::vec3>& Screen::pixels() const { return m_textureData; }
-std::vector<glm::vec3>& Screen::pixels() { return m_textureData; }
+// (clear, setPixel, resolution, pixels, indexAt: the reference's own lines, camera_screen_tu.cpp)
 
 // ---- Trackball -------------------------------------------------------------
 // The harness passes a pointer to a float holding the aspect ratio where the
@@ -69,26 +55,5 @@ Trackball::Trackball(Window* pWindow, float fovy, const glm::vec3& lookAt, float
     , m_rotationEulerAngles(rotationX, rotationY, 0)
 {
 }
-void Trackball::setCamera(const glm::vec3 lookAt, const glm::vec3 rotations, const float dist)
-{
-    m_lookAt = lookAt;
-    m_rotationEulerAngles = rotations;
-    m_distanceFromLookAt = dist;
-}
-glm::vec3 Trackball::lookAt() const { return m_lookAt; }
-glm::vec3 Trackball::rotationEulerAngles() const { return m_rotationEulerAngles; }
-float Trackball::distanceFromLookAt() const { return m_distanceFromLookAt; }
-glm::vec3 Trackball::position() const
-{
-    const glm::quat q(m_rotationEulerAngles);
-    return m_lookAt + q * glm::vec3(0, 0, -m_distanceFromLookAt);
-}
-Ray Trackball::generateRay(const glm::vec2& pixel) const
-{
-    const glm::quat q(m_rotationEulerAngles);
-    Ray r;
-    r.origin = position();
-    r.direction = q * glm::normalize(glm::vec3(-pixel.x * m_halfScreenSpaceWidth, pixel.y * m_halfScreenSpaceHeight, 1.0f));
-    r.t = std::numeric_limits<float>::max();
-    return r;
-}
+// (setCamera, position, lookAt, rotationEulerAngles, distanceFromLookAt, generateRay: the reference's
+// own lines, camera_screen_tu.cpp)

@@ -729,7 +729,7 @@ void ref_kat_glossy(const rtx_ray* reflection, float degreeBlur, int nRays, uint
         out[i].t = rays[i].t;
     }
 }
-// camera: position + n rays for ndc points (harness Trackball; see hooks.cpp)
+// camera: position + n rays for ndc points (the reference's Trackball methods; see camera_screen_tu.cpp)
 void ref_kat_camera(const rtx_camera* cam, float fovy, float aspect, const float* ndc, int n, rtx_ray* out)
 {
     Trackball camera(reinterpret_cast<Window*>(&aspect), fovy, v3(cam->look_at), cam->distance, cam->euler[0], cam->euler[1]);

@@ -37,6 +37,13 @@ struct Huffman {
 
     void build(const int counts[16], const uint8_t* values, int n, const std::string& file)
     {
+        // the table is checked as a whole before anything is written: a length with more codes
+        // than its bits can tell apart would index past the lookup table below
+        for (int len = 1, code = 0; len <= 16; len++, code <<= 1) {
+            code += counts[len - 1];
+            if (code > (1 << len))
+                throw RtIoError(file + ": JPEG Huffman table has too many codes of one length");
+        }
         std::memcpy(symbols, values, size_t(n));
         std::memset(fast, 0, sizeof(fast));
         int code = 0, index = 0;
@@ -51,8 +58,6 @@ struct Huffman {
                 }
             }
             maxCode[len] = code - 1; // -1 below minCode when the length is unused
-            if (code > (1 << len))
-                throw RtIoError(file + ": JPEG Huffman table has too many codes of one length");
             code <<= 1;
         }
         defined = true;

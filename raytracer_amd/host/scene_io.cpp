@@ -551,15 +551,19 @@ Image decodeBmp(const std::vector<unsigned char>& d, const std::string& file)
     if (w <= 0 || h <= 0 || w > 65536 || h > 65536)
         throw RtIoError(file + ": bad BMP size");
     const size_t stride = (size_t(w) * size_t(bpp) / 8 + 3) & ~size_t(3);
+    // (both are the file's own words: the header must lie inside the file and the pixels behind it)
+    if (14 + size_t(headerSize) > d.size() || size_t(offset) < 14 + size_t(headerSize))
+        throw RtIoError(file + ": bad BMP header size or pixel offset");
     if (size_t(offset) + stride * size_t(h) > d.size())
         throw RtIoError(file + ": truncated BMP pixel data");
-    const unsigned char* palette = &d[14 + headerSize];
+    const unsigned char* palette = nullptr;
     uint32_t colours = le32(&d[46]);
     if (bpp == 8) {
         if (colours == 0)
             colours = 256;
         if (14 + size_t(headerSize) + 4 * size_t(colours) > d.size() || colours > 256)
             throw RtIoError(file + ": truncated BMP palette");
+        palette = d.data() + 14 + size_t(headerSize);
     }
     Image img;
     img.width = w;

@@ -192,6 +192,15 @@ def test_jpeg_reader_matches_the_reference_image_class(tmp_path):
         (tmp_path / (name + ".jpg")).write_bytes(data)
         with pytest.raises(RuntimeError):
             engine.load_image(str(tmp_path / (name + ".jpg")))
+    # a Huffman table that claims more codes of one length than the length can tell apart is refused
+    # before its lookup table is filled (3 and 255 one-bit codes)
+    dht = raw.index(b"\xff\xc4")
+    for count in (3, 255):
+        values = bytes(range(count))
+        segment = b"\xff\xc4" + (2 + 1 + 16 + count).to_bytes(2, "big") + b"\x00" + bytes([count]) + bytes(15) + values
+        (tmp_path / f"dht{count}.jpg").write_bytes(raw[:dht] + segment + raw[dht:])
+        with pytest.raises(RuntimeError, match="Huffman"):
+            engine.load_image(str(tmp_path / f"dht{count}.jpg"))
 
 
 def test_bmp_reader(tmp_path):
@@ -218,6 +227,12 @@ def test_bmp_reader(tmp_path):
     (tmp_path / "d.bmp").write_bytes((header(24, 5) + rows24)[:80])
     with pytest.raises(RuntimeError):
         engine.load_image(str(tmp_path / "d.bmp"))
+    # a header size or pixel offset that points outside the file (or into the header) is refused
+    good = header(24, 5) + rows24
+    for name, data in (("e", good[:14] + struct.pack("<I", 0x7fffff00) + good[18:]), ("f", good[:10] + struct.pack("<I", 20) + good[14:])):
+        (tmp_path / (name + ".bmp")).write_bytes(data)
+        with pytest.raises(RuntimeError, match="header size or pixel offset"):
+            engine.load_image(str(tmp_path / (name + ".bmp")))
 
 
 def test_empty_scene_and_single_triangle():
