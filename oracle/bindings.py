@@ -17,7 +17,8 @@ from raytracer_amd import abi
 from raytracer_amd.scene import SceneData
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+# (RTX_ORACLE_SO: another build of the restatement, e.g. the sanitizer build of `make asan`)
+ORACLE_SO = os.environ.get("RTX_ORACLE_SO") or os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libref.so")
 
 vp = C.c_void_p

@@ -16,7 +16,8 @@ from .scene import SceneData
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.path.join(_HERE, "librtx_hip.so")
-HOST_SO = os.path.join(_HERE, "librtx_host.so")
+# (RTX_HOST_SO: another build of the host library, e.g. the sanitizer build of `make asan`)
+HOST_SO = os.environ.get("RTX_HOST_SO") or os.path.join(_HERE, "librtx_host.so")
 
 vp = C.c_void_p
 _host = None

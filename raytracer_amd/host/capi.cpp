@@ -300,18 +300,17 @@ void rtxh_flat_counts(const void* fl, int64_t* out)
 void rtxh_flat_copy(const void* fl, rtx_node* nodes, rtx_tri* tris, rtx_tri_attr* attrs, rtx_material* mats, rtx_texture* textures, float* texels)
 {
     const auto* f = static_cast<const FlatScene*>(fl);
-    if (nodes)
-        std::memcpy(nodes, f->nodes.data(), f->nodes.size() * sizeof(rtx_node));
-    if (tris)
-        std::memcpy(tris, f->tris.data(), f->tris.size() * sizeof(rtx_tri));
-    if (attrs)
-        std::memcpy(attrs, f->attrs.data(), f->attrs.size() * sizeof(rtx_tri_attr));
-    if (mats)
-        std::memcpy(mats, f->materials.data(), f->materials.size() * sizeof(rtx_material));
-    if (textures)
-        std::memcpy(textures, f->textures.data(), f->textures.size() * sizeof(rtx_texture));
-    if (texels)
-        std::memcpy(texels, f->texels.data(), f->texels.size() * sizeof(float));
+    // (an empty vector's data() may be null, which memcpy must not be handed even for 0 bytes)
+    auto copy = [](void* dst, const auto& v) {
+        if (dst && !v.empty())
+            std::memcpy(dst, v.data(), v.size() * sizeof(v[0]));
+    };
+    copy(nodes, f->nodes);
+    copy(tris, f->tris);
+    copy(attrs, f->attrs);
+    copy(mats, f->materials);
+    copy(textures, f->textures);
+    copy(texels, f->texels);
 }
 void rtxh_flat_root(const void* fl, int32_t* ref, float* lo, float* hi)
 {
