@@ -16,8 +16,9 @@ rendered, and every frame is assembled on rank 0 inside the timed region.
 
 data/dragon.obj is not part of the reference checkout, so the geometry is the
 seeded stand-in of raytracer_amd.scene.dragon_standin (81 920 triangles, unit
-ball, same light and camera as SceneType::Dragon); pass --obj-npz to use a real
-mesh exported as a scene .npz.
+ball, same light and camera as SceneType::Dragon); pass --obj dragon.obj to use the
+real mesh (loaded and normalised as the reference does), or --obj-npz for a scene
+saved by raytracer_amd.scene.SceneData.save.
 
 One JSON line is printed by rank 0.
 """
@@ -95,12 +96,24 @@ def workload(name, args):
     from raytracer_amd import abi
     from raytracer_amd.scene import SceneData, dragon_scene, instanced_scene, winding_dragon_scene
     base = dict(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
+    def dragon():
+        """SceneType::Dragon (src/scene.cpp:68-73): the mesh, one white point light at (-1, 1, -1).  A user's
+        OBJ goes through the host loader with the reference's unit normalisation (framework/src/mesh.cpp:151-176)."""
+        if args.obj:
+            from raytracer_amd import engine
+            s = engine.load_obj(args.obj, normalize=True)
+            s.lights.append(abi.point_light((-1, 1, -1), (1, 1, 1)))
+            return s, f"{os.path.basename(args.obj)} ({s.n_triangles} tris, user-supplied, scaled to the unit cube)"
+        if args.obj_npz:
+            s = SceneData.load(args.obj_npz)
+            return s, f"{os.path.basename(args.obj_npz)} ({s.n_triangles} tris, user-supplied scene file)"
+        s = dragon_scene()
+        return s, f"dragon stand-in ({s.n_triangles} tris, seeded; dragon.obj is absent from the reference checkout)"
     if name == "headline":
-        scene = SceneData.load(args.obj_npz) if args.obj_npz else dragon_scene()
+        scene, what = dragon()
         return dict(scene=scene, features=abi.features(**base), params=dict(driver=abi.DRIVER_MRAYS, samples=args.spp), ref_mode=0,
                     metric="Mrays/s (primary+secondary), dragon 1080p 16spp",
-                    text=f"dragon stand-in ({scene.n_triangles} tris, seeded; dragon.obj is absent from the reference checkout) "
-                         f"{args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light")
+                    text=f"{what} {args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light")
     if name == "winding":
         scene = winding_dragon_scene()
         return dict(scene=scene, features=abi.features(**base), params=dict(driver=abi.DRIVER_MRAYS, samples=args.spp), ref_mode=0,
@@ -108,7 +121,7 @@ def workload(name, args):
                     text=f"winding dragon stand-in ({scene.n_triangles} tris, seeded: coiled body, thin wings, legs, spikes) "
                          f"{args.width}x{args.height}, {args.spp} spp jittered, Phong + hard shadows, 1 point light")
     if name == "area_glossy":
-        scene = dragon_scene()
+        scene, what = dragon()
         scene.lights = [abi.parallelogram_light((-0.2, 0.9, 0.0), (0.4, 0, 0), (0, 0, 0.4), (1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1))]
         for m in scene.meshes:   # a glossy material: ks != 0, shininess 50
             m.material[3:6] = 0.5
@@ -116,7 +129,7 @@ def workload(name, args):
         f = abi.features(**dict(base, hard_shadow=0, soft_shadow=1, recursive=1, glossy_reflection=1))
         return dict(scene=scene, features=f, params=dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=4), ref_mode=1,
                     metric="Mrays/s (primary+secondary), dragon 1080p area light 64 + glossy depth 4",
-                    text=f"dragon stand-in ({scene.n_triangles} tris, seeded, ks 0.5, shininess 50) {args.width}x{args.height}, 1 spp, "
+                    text=f"{what}, ks 0.5, shininess 50, {args.width}x{args.height}, 1 spp, "
                          "one parallelogram light with 64 shadow samples, glossy reflections (5 rays) to depth 4")
     if name == "big_scene":
         scene = instanced_scene(122)
@@ -125,6 +138,29 @@ def workload(name, args):
                     text=f"122 instances of the dragon stand-in baked to {scene.n_triangles} triangles, {args.width}x{args.height}, "
                          f"{args.spp} spp jittered, Phong + hard shadows, 1 point light")
     sys.exit(f"unknown workload {name}")
+
+
+def measured_counters(workload_name):
+    """Per-launch hardware counters of the dominant kernel from the newest rocprofv3 summary committed under
+    profiles/ (tools/profile_counters.sh + tools/round_profiles.py): SQ_INSTS_VALU, HBM bytes (2 x FETCH_SIZE +
+    WRITE_SIZE, KB), the file they come from, and whether the library they were taken on is the one loaded now."""
+    import glob
+    import hashlib
+    suffix = "" if workload_name == "headline" else "_" + workload_name
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{suffix}_render_counters.json")))
+    if not files:
+        return {}
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    c = d.get("counters_per_launch_mean", {})
+    out = {"file": os.path.relpath(files[-1], ROOT), "SQ_INSTS_VALU": c.get("SQ_INSTS_VALU")}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        out["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    with open(os.path.join(ROOT, "raytracer_amd", "librtx_hip.so"), "rb") as fh:
+        now = hashlib.sha256(fh.read()).hexdigest()
+    # (a summary without a hash predates the check: it cannot be told apart from a stale one)
+    out["stale"] = d.get("library_sha256") != now
+    return out
 
 
 def valu_peak(waves_per_simd=4):
@@ -156,6 +192,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--obj", default=None, help="Wavefront OBJ (with its MTL / textures beside it) to use instead of the stand-in, e.g. a user-supplied dragon.obj: "
+                                                "loaded and scaled into the unit cube as the reference's SceneType::Dragon does (loadMesh(..., normalize = true))")
     ap.add_argument("--obj-npz", default=None, help="scene .npz (raytracer_amd.scene.SceneData.save) to use instead of the stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
@@ -372,6 +410,39 @@ def main():
                        "build_ms": round(info["build_ms"], 2), "host_records_upload_build_s": round(t_dev, 3)}
         gpu2.close()
 
+    # for the record, two harder views of the same scene (kernel time, one frame after the other):
+    # a camera close enough that the mesh fills the screen, and a camera that moves between frames, so
+    # that no frame finds a block order learnt from an identical predecessor nor camera-relative
+    # records made for its position (every frame remakes them: that kernel is inside the time)
+    extra = {}
+    if not grouped and not args.no_every_block and args.workload in ("headline", "winding"):
+        def timed_views(views, reps):
+            cams = [engine.device_camera(make_camera(**v), args.width, args.height) for v in views]
+            rays, traced = [], []
+            for c2 in cams:       # counted once, untimed
+                s4 = abi.Stats()
+                check(hip.rtx_render_device(dscene, C.byref(c2), C.byref(features), C.byref(rp), C.c_void_p(frame.data_ptr()), C.byref(s4)))
+                rays.append(s4.rays)
+                traced.append(s4.rays_traced)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                for c2 in cams:
+                    check(hip.rtx_render_device(dscene, C.byref(c2), C.byref(features), C.byref(rp), C.c_void_p(frame.data_ptr()), None))
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / (reps * len(cams))
+            return ms, sum(rays) / len(rays), sum(traced) / len(traced)
+        ms, r, tr = timed_views([dict(distance=1.2)], max(args.steps, 4))
+        extra["screen_filling_view"] = {"camera": "distance 1.2 (default 3)", "ms_per_frame": round(ms, 4), "rays_per_frame": int(r), "rays_traced": int(tr),
+                                        "mrays_s": round(r / ms / 1e3, 1), "mrays_s_on_rays_traced": round(tr / ms / 1e3, 1)}
+        orbit = [dict(rotation_degrees=(20 + 9 * ((7 * i) % 5 - 2), 20 + 37 * i, 0), distance=3.0 - 0.11 * (i % 7)) for i in range(max(args.steps, 8))]
+        ms, r, tr = timed_views(orbit, 1)
+        extra["moving_camera"] = {"camera": f"{len(orbit)} different poses, one per frame (orbit in steps of 37 degrees, tilt and distance varied); includes remaking the camera-relative records",
+                                  "ms_per_frame": round(ms, 4), "rays_per_frame": int(r), "rays_traced": int(tr),
+                                  "mrays_s": round(r / ms / 1e3, 1), "mrays_s_on_rays_traced": round(tr / ms / 1e3, 1)}
+
     if rank == 0 and args.check and grouped:
         ref = torch.zeros_like(frame)
         one = make_params(args.width, args.height, tile_size=args.tile, **wl["params"])
@@ -412,44 +483,56 @@ def main():
             cb, n_aabb, n_tri = (None, None, None)
             if not args.no_cpu_baseline:
                 cb, n_aabb, n_tri = cpu_baseline(scene, features, cam_in, args, wl)
-            # measured counters of the same command, committed with the rocprofv3 summaries they come from
-            traffic, valu_instr = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-            if os.path.exists(tpath) and args.workload == "headline":
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get("bytes_per_launch")
-            cpath = os.path.join(ROOT, "profiles", "r02_render_counters.json")
-            if os.path.exists(cpath) and args.workload == "headline":
-                with open(cpath) as fh:
-                    valu_instr = json.load(fh).get("counters_per_launch_mean", {}).get("SQ_INSTS_VALU")
-            if n_aabb is not None:
-                alg = algorithmic_bytes(rays_frame, shaded_frame, pixels, n_aabb, n_tri)
-                achieved = alg / (kernel_ms * 1e-3) / 1e9
-                out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            # The hardware counters of this command come from rocprofv3 passes (they cannot be read from inside
+            # the run): the newest summary under profiles/ carries the hash of the library it was taken on, and
+            # the line says so when that is not the library running now.
+            # (they describe the workload's own command: another mesh or frame size has none)
+            own_command = not args.obj and not args.obj_npz and args.spp == 16 and args.tile == 32 and \
+                (args.width, args.height) == ((3840, 2160) if args.workload == "big_scene" else (1920, 1080))
+            counters = measured_counters(args.workload) if own_command else {}
+            traffic = counters.get("hbm_bytes_per_launch")
+            valu_instr = counters.get("SQ_INSTS_VALU")
+            vp = valu_peak()
+            if valu_instr is not None and vp is not None:
+                # The kernel is bound by vector-ALU issue (pointer chasing through cache-resident records: no
+                # dense contraction, 4 % of the HBM rate).  Peak: a SIMD issues one wave64 instruction every
+                # two cycles at best (a wave64 instruction occupies the 32-lane ALU for two passes).
+                simds = torch.cuda.get_device_properties(dev).multi_processor_count * 4
+                peak = 0.5 * simds * vp["clock_mhz"] * 1e6 / 1e9
+                achieved = valu_instr / (kernel_ms * 1e-3) / 1e9
+                out["roofline"] = {"bound": "valu issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                                   "frac": round(achieved / peak, 4), "traffic": traffic,
                                    "kernel": "renderKernel" if args.workload != "area_glossy" else "renderKernel (walk) + lightKernel + resolveKernel",
                                    # one frame after the other on one stream (HIP events over args.steps frames), the figure
                                    # the kernel trace's average duration agrees with; the timed region above keeps
                                    # frames_in_flight frames on the chip at once
-                                   "kernel_ms": round(kernel_ms, 4),
-                                   "algorithmic_bytes_per_launch": int(alg), "box_tests_per_ray": round(n_aabb, 3),
-                                   "tri_tests_per_ray": round(n_tri, 3)}
-                if traffic is not None:
-                    # what the kernel really moves to and from memory: the scene is cache-resident, so
-                    # this, not the algorithmic figure, is the kernel's place on the HBM roofline
-                    out["roofline"]["frac_measured"] = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                   "kernel_ms": round(kernel_ms, 4), "valu_instr_per_launch": int(valu_instr),
+                                   "peak_is": f"0.5 wave64 instructions per cycle per SIMD x {simds} SIMDs x the clock measured now ({round(vp['clock_mhz'])} MHz)",
+                                   # the same rate against what a SIMD issues of the kernel's OWN instruction mix (a third of
+                                   # its instructions are 4.3-cycle kinds: compares, selects, min / max, lane reads), measured
+                                   # now on this GPU at the kernel's 4 waves per SIMD (tools/valu_peak.hip)
+                                   "frac_of_mix_ceiling": round(achieved / vp["chip_ginstr_s"], 4),
+                                   "mix_ceiling_instr_per_cycle_per_simd": round(vp["ipc"], 4), "v_mul_f32_instr_per_cycle_per_simd": round(vp["ipc_mul"], 4),
+                                   "counters_from": counters.get("file"), "counters_stale": counters.get("stale")}
                 if traced_all_ms is not None:
                     out["roofline"]["kernel_ms_every_block_traced"] = round(traced_all_ms, 4)
                     out["roofline"]["mrays_s_every_block_traced"] = round(rays_frame / traced_all_ms / 1e3, 1)
-            if valu_instr is not None:
-                vp = valu_peak()
-                if vp is not None:
-                    achieved = valu_instr / (kernel_ms * 1e-3) / 1e9
-                    out["roofline_valu"] = {"bound": "valu issue", "achieved": round(achieved, 1), "peak": round(vp["chip_ginstr_s"], 1), "unit": "G wave-instr/s",
-                                            "frac": round(achieved / vp["chip_ginstr_s"], 4), "valu_instr_per_launch": int(valu_instr),
-                                            "peak_is": "measured now on this GPU: the instruction mix of the kernel's traversal loop (static proportions of its ISA, tools/valu_peak.hip) at the kernel's 4 waves per SIMD",
-                                            "peak_instr_per_cycle_per_simd": round(vp["ipc"], 4), "peak_v_mul_f32_instr_per_cycle_per_simd": round(vp["ipc_mul"], 4),
-                                            "clock_mhz": round(vp["clock_mhz"])}
+            if n_aabb is not None:
+                # The byte count of an implementation that fetched every box and triangle of the reference's visit
+                # rule from memory, per ray; this kernel does not move those bytes (one scalar-cache fetch serves 64
+                # lanes, the scene is cache-resident, blocks that cannot see the scene are never traced), so the
+                # nominal fraction can exceed 1 and only frac_measured (HBM counters / time / peak) is a roofline.
+                alg = algorithmic_bytes(rays_frame, shaded_frame, pixels, n_aabb, n_tri)
+                nominal = alg / (kernel_ms * 1e-3) / 1e9
+                out["roofline_hbm_nominal"] = {"bound": "hbm", "achieved": round(nominal, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": round(nominal / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(alg),
+                                               "box_tests_per_ray": round(n_aabb, 3), "tri_tests_per_ray": round(n_tri, 3), "traffic": traffic}
+                if traffic is not None:
+                    out["roofline_hbm_nominal"]["frac_measured"] = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                if "roofline" not in out:   # (no counter summary for this workload under profiles/: the nominal figure alone)
+                    out["roofline"] = dict(out["roofline_hbm_nominal"], kernel_ms=round(kernel_ms, 4))
+            if extra:
+                out["config"].update(extra)
             if cb is not None:
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

@@ -965,6 +965,29 @@ def test_several_ranks_rehearsed_on_one_gpu(gpu_device, workload, ranks):
     assert line["config"]["rays_per_frame"] == line["config"]["primary"] + line["config"]["shadow"] + line["config"]["bounce"]
 
 
+def test_bench_takes_a_wavefront_obj(gpu_device):
+    """bench.py --obj PATH: a user's mesh (the dragon.obj the reference's checkout lacks) goes through the host
+    loader with the reference's unit normalisation and needs no conversion step; the line carries a roofline,
+    the CPU baseline and the two harder views."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--obj", os.path.join(cases.GOLDEN, "obj", "mixed.obj"), "--steps", "3", "--warmup", "1",
+                        "--width", "320", "--height", "184"], capture_output=True, text=True, timeout=115, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert "mixed.obj" in line["config"]["workload"] and "user-supplied" in line["config"]["workload"]
+    assert line["value"] > 0 and line["config"]["rays_per_frame"] >= 320 * 184 * 16
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["kernel_ms"] > 0
+    assert line["cpu_baseline"]["value"] > 0
+    assert line["config"]["screen_filling_view"]["mrays_s"] > 0 and line["config"]["moving_camera"]["mrays_s"] > 0
+
+
 def test_render_into_page_locked_host_memory(gpu_device):
     """rtx_render into a buffer from rtx_host_alloc gives the frame it gives into plain host
     memory (the copy back takes the direct path instead of the runtime's staging buffer)."""

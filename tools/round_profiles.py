@@ -4,6 +4,7 @@ files kept under profiles/:  <tag>_kernel_stats.csv (the kernel trace's per-kern
 <tag>_render_counters.json (per-launch counter means of the render kernel) and
 <tag>_hbm_traffic.json (HBM bytes per launch: FETCH_SIZE doubled, because gfx950 tallies a
 128-byte read request as 64 bytes, plus WRITE_SIZE; both counters are in KB).
+The tag is r<round> for the headline workload and r<round>_<workload> for another (bench.py looks them up so).
 Usage: tools/round_profiles.py <rocprof outdir> <tag> [kernel name substring]"""
 import csv, glob, json, os, shutil, subprocess, sys
 
@@ -12,6 +13,11 @@ kernel = sys.argv[3] if len(sys.argv) > 3 else "renderKernel"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 summary = json.loads(subprocess.check_output([sys.executable, os.path.join(root, "tools", "summarize_counters.py"), d, kernel]))
+# the library the counters were taken on (the tree that went to the GPU box is this one): bench.py reports
+# "counters_stale" when the library it runs is another
+import hashlib
+with open(os.path.join(root, "raytracer_amd", "librtx_hip.so"), "rb") as fh:
+    summary["library_sha256"] = hashlib.sha256(fh.read()).hexdigest()
 with open(os.path.join(prof, f"{tag}_render_counters.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
 ks = glob.glob(os.path.join(d, "trace", "*kernel_stats.csv"))
