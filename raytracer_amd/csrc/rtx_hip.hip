@@ -2266,6 +2266,30 @@ __global__ void __launch_bounds__(256) originFrameKernel(const float4* waveNodes
     }
 }
 
+// The skip-ahead tables of the driver-level engine (see RenderArgs::jumpX): entry i of each is a
+// power of that table's step, g^i, gRow^i, gS^i mod 2^31 - 1, by square-and-multiply per entry.
+RTX_DEV uint32_t powMod(uint64_t base, uint32_t e)
+{
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1u)
+            r = mulMod(r, base);
+        base = mulMod(base, base);
+        e >>= 1;
+    }
+    return uint32_t(r);
+}
+__global__ void __launch_bounds__(256) jumpTablesKernel(uint32_t* jump, uint32_t maxDim, uint32_t W, uint32_t H, uint32_t nS, uint64_t g, uint64_t gRow, uint64_t gS)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < W)
+        jump[i] = powMod(g, i);
+    if (i < H)
+        jump[maxDim + i] = powMod(gRow, i);
+    if (i < nS)
+        jump[2 * maxDim + i] = powMod(gS, i);
+}
+
 __global__ void detileKernel(const float* tiles, float* out, int W, int H, int ts, int tilesX, int tilesY, int world, int tilesPerRank)
 {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -3251,25 +3275,13 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         const int ns = std::min(A.samples, a->jumpMaxSamples);
         A.jumpSamples = ns;
         if (a->jumpW != A.W || a->jumpH != A.H || a->jumpS != A.samples || a->jumpD != d) {
-            // (the fixed arena's path must not allocate: its tables fit the stack)
-            uint32_t onStack[kFixedJumpWords];
-            std::vector<uint32_t> onHeap(fixedArena ? 0 : size_t(A.W) + size_t(A.H) + size_t(ns));
-            uint32_t* const t = fixedArena ? onStack : onHeap.data();
+            // (filled by a kernel on the stream: no host table, no copy from pageable memory and no wait, so
+            // the first frame of a shape is queued like every other one)
             const uint64_t perPixel = uint64_t(d) * uint64_t(A.samples);
             const uint64_t g = hostPowMod(16807, perPixel), gRow = hostPowMod(g, uint64_t(A.W)), gS = hostPowMod(16807, uint64_t(d));
-            uint64_t v = 1;
-            for (int x = 0; x < A.W; x++, v = hostMulMod(v, g))
-                t[size_t(x)] = uint32_t(v);
-            v = 1;
-            for (int y = 0; y < A.H; y++, v = hostMulMod(v, gRow))
-                t[size_t(A.W) + size_t(y)] = uint32_t(v);
-            v = 1;
-            for (int i = 0; i < ns; i++, v = hostMulMod(v, gS))
-                t[size_t(A.W) + size_t(A.H) + size_t(i)] = uint32_t(v);
-            HIP_TRY(hipMemcpyAsync(a->jump, t, size_t(A.W) * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(a->jump + a->jumpMaxDim, t + A.W, size_t(A.H) * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(a->jump + 2 * a->jumpMaxDim, t + A.W + A.H, size_t(ns) * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream)); // t goes out of scope
+            const uint32_t entries = uint32_t(std::max(std::max(A.W, A.H), ns));
+            hipLaunchKernelGGL(jumpTablesKernel, dim3((entries + 255u) / 256u), dim3(256), 0, c->stream, a->jump, uint32_t(a->jumpMaxDim), uint32_t(A.W), uint32_t(A.H), uint32_t(ns), g, gRow, gS);
+            HIP_TRY(hipGetLastError());
             a->jumpW = A.W, a->jumpH = A.H, a->jumpS = A.samples, a->jumpD = d;
         }
     }
@@ -4281,6 +4293,11 @@ rtx_scene* rtx_scene_build_device(const rtx_scene_desc* d)
     O.idOrder = static_cast<int32_t*>(keep(size_t(n) * 4));
     float rootBox[6] = {}, cut[1 + kMaxCutBoxes * 6] = {};
     if (ok) {
+        // (the padding record is read -- never used -- by the pair fetch and copied into origin frames: zero, as rtx_scene_create leaves it)
+        e = hipMemsetAsync(reinterpret_cast<unsigned char*>(O.waveTris) + size_t(n) * 96, 0, 96, stream);
+        ok = e == hipSuccess;
+    }
+    if (ok) {
         hipLaunchKernelGGL(triangleRecordsKernel, perTri, block, 0, stream, B, O);
         hipLaunchKernelGGL(nodeRecordsKernel, perNode, block, 0, stream, B, O);
         hipLaunchKernelGGL(wideRecordsKernel, perNode, block, 0, stream, B, O);
@@ -4444,6 +4461,15 @@ int rtx_render_device_static(const rtx_scene* scene, const rtx_camera* cam, cons
     if (g_ctx->slot != 0) {
         setErr("rtx_render_device_static: the fixed workspace belongs to frame slot 0 (this thread has selected slot %d)", g_ctx->slot);
         return RTX_ERR_INVALID;
+    }
+    if (stats) {
+        // reading the counters back waits for the frame and copies to the host: not while the stream is being captured
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(g_ctx->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+            setErr("rtx_render_device_static: stats must be NULL while the stream is being captured (reading them back waits for the frame)");
+            return RTX_ERR_INVALID;
+        }
+        (void)hipGetLastError();
     }
     return renderImpl(scene, cam, f, p, dOut, false, stats, t0, true);
 }

@@ -66,6 +66,18 @@ def test_static_workspace_entry_point_matches_render_device(gpu_device):
     (a, ra), = _frames(hip, static, g2.device_scene(), cam, ff, rp)
     (b, rb), = _frames(hip, hip.rtx_render_device, g2.device_scene(), cam, ff, rp)
     assert ra == rb and np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+    # (rtx_render_device renders such frames in three passes, this entry point in one kernel: the same frames
+    # for another driver and for one rank's tiles of a partitioned frame, whose other pixels stay untouched)
+    for w, h, kw in ((56, 40, dict(driver=abi.DRIVER_MRAYS, samples=3, shadow_samples=70, glossy_rays=3, ray_depth=1)),
+                     (72, 48, dict(shadow_samples=8, glossy_rays=2, ray_depth=2, tile_size=16, tile_rank=1, tile_world=3)),
+                     (48, 48, dict(driver=abi.DRIVER_DOF, samples=4, shadow_samples=20, ray_depth=0, tile_size=8, tile_rank=0, tile_world=2))):
+        cam = engine.device_camera(make_camera(), w, h)
+        rp = make_params(w, h, **kw)
+        (a, ra), = _frames(hip, static, g2.device_scene(), cam, ff, rp)
+        (b, rb), = _frames(hip, hip.rtx_render_device, g2.device_scene(), cam, ff, rp)
+        assert ra == rb, (w, h, ra, rb)
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b)), f"{w}x{h}: frames differ"
+        assert (a == -5.0).any() == ("tile_world" in kw)
     g2.close()
     # beyond the fixed workspace: refused with a message, nothing launched
     import torch
@@ -77,4 +89,56 @@ def test_static_workspace_entry_point_matches_render_device(gpu_device):
     many = make_params(4096, 4096, tile_size=1024)   # fits
     many_blocks = make_params(4096, 4090, tile_size=1024)
     assert hip.rtx_tiles_per_rank(C.byref(many)) == 16 and hip.rtx_tiles_per_rank(C.byref(many_blocks)) == 16
+    gpu.close()
+
+
+def test_static_entry_point_under_stream_capture_and_without_allocation(gpu_device):
+    """What the entry point is for.  (1) Frames of shapes the workspace has not seen (their sampler
+    tables are made on the way, by a kernel on the stream) leave the GPU's free memory where it
+    was.  (2) A call with stats == NULL is captured into a HIP graph -- a capture in which any
+    allocation, copy from pageable memory or wait would fail -- and the graph's replays give
+    rtx_render_device's frame; with a stats pointer the call is refused while capturing."""
+    import torch
+    hip = engine.hip_lib()
+    static = hip.rtx_render_device_static
+    static.argtypes = hip.rtx_render_device.argtypes
+    scene = cases.load_scene("monkey")
+    f = abi.features(**cases.BASE)
+    gpu = GpuEngine(scene, f)
+    dsc = gpu.device_scene()
+    torch.cuda.synchronize()
+    out = torch.zeros((90, 130, 3), dtype=torch.float32, device="cuda:0")
+    free0 = torch.cuda.mem_get_info()[0]
+    for w, h, kw in ((130, 90, dict(driver=abi.DRIVER_MRAYS, samples=3)), (75, 41, dict(driver=abi.DRIVER_DOF, samples=6)),
+                     (64, 64, dict(driver=abi.DRIVER_MOTION_BLUR, samples=5, prev_camera=engine.device_camera(make_camera(rotation_degrees=(21, 19, 0)), 64, 64)))):
+        cam = engine.device_camera(make_camera(), w, h)
+        rp = make_params(w, h, **kw)
+        assert static(dsc, C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(out.data_ptr()), None) == 0, hip.rtx_last_error()
+    assert hip.rtx_synchronize() == 0
+    assert torch.cuda.mem_get_info()[0] == free0, "the static entry point changed the GPU's free memory"
+
+    w, h = 112, 80
+    cam = engine.device_camera(make_camera(), w, h)
+    rp = make_params(w, h, driver=abi.DRIVER_MRAYS, samples=7)   # (a shape new to the workspace: the table kernel is part of the capture)
+    (want, _), = _frames(hip, hip.rtx_render_device, dsc, cam, f, rp)
+    frame = torch.full((h, w, 3), -5.0, dtype=torch.float32, device="cuda:0")
+    side = torch.cuda.Stream()
+    assert hip.rtx_set_stream(C.c_void_p(side.cuda_stream)) == 0
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            st = abi.Stats()
+            refused = static(dsc, C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(frame.data_ptr()), C.byref(st))
+            message = hip.rtx_last_error()
+            rc = static(dsc, C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(frame.data_ptr()), None)
+        assert refused == -1 and b"captured" in message
+        assert rc == 0, hip.rtx_last_error()
+        for _ in range(3):   # (the second and third replay run in the order measured by the one before)
+            frame.fill_(-5.0)
+            graph.replay()
+            torch.cuda.synchronize()
+            got = frame.cpu().numpy()
+            assert np.array_equal(got, want), "a replayed graph's frame differs from rtx_render_device's"
+    finally:
+        assert hip.rtx_set_stream(None) == 0
     gpu.close()
