@@ -191,16 +191,32 @@ typedef enum rtx_driver {
     RTX_DRIVER_PLAIN = 0,         /* renderRayTracing               src/render.cpp:69-90   */
     RTX_DRIVER_MRAYS = 1,         /* renderRayTracingMRaysPerPixel  src/render.cpp:152-183 */
     RTX_DRIVER_DOF = 2,           /* renderRayTracingDepthOfField   src/render.cpp:92-126  */
-    RTX_DRIVER_TRANSPARENCY = 3,  /* renderRayTracingTransparency   src/render.cpp:129-150; at most 16
-                                     translucent layers per camera ray (see rtx_stats.layer_overflows) */
-    RTX_DRIVER_MOTION_BLUR = 4    /* renderRayTracingMotionBlur     src/render.cpp:190-253 (second and later calls) */
+    RTX_DRIVER_TRANSPARENCY = 3,  /* renderRayTracingTransparency   src/render.cpp:129-150 (any number of
+                                     translucent layers per camera ray; see rtx_stats.layer_overflows) */
+    RTX_DRIVER_MOTION_BLUR = 4,   /* renderRayTracingMotionBlur     src/render.cpp:190-253 (second and later calls) */
+    /* The four sampling drivers above in ONE frame.  The reference's router makes them mutually
+     * exclusive (src/main.cpp:50-63), so the combination is this library's own: per pixel
+     * time_steps x lens_samples x samples camera samples, sample s = (t * lens_samples + l) * samples + j,
+     * each built from the drivers' own pieces in the order time, pixel, lens:
+     *   time_steps > 1    the pose of src/render.cpp:224-235 at w = (jitter + t) / time_steps (one draw)
+     *   samples > 1       the pixel position of src/render.cpp:170-174 (two draws)
+     *   lens_samples > 1  the origin and direction of src/dof.cpp:9-39 about this sample's own camera ray (three draws)
+     *   transparency != 0 calculateColorTransparency on the sample's ray (src/transparency.cpp:6-20), else getFinalColor
+     * A dimension of size 1 is off and draws nothing; the draws come from the reference's
+     * sequential engine, sample after sample.  The sum runs in sample order and is scaled like
+     * src/render.cpp:178 (times 1 / count), like :249 (divided by count) when only time_steps is on,
+     * and not at all for a single sample.  So each driver is the composition with the other
+     * dimensions off, bit for bit: samples alone = MRAYS, lens_samples alone = DOF, time_steps alone =
+     * MOTION_BLUR, transparency alone = TRANSPARENCY, nothing = PLAIN. */
+    RTX_DRIVER_COMPOSED = 5
 } rtx_driver;
 
 typedef struct rtx_render_params {
     int32_t  width, height;
     int32_t  driver;          /* rtx_driver                                     */
-    int32_t  ray_depth;       /* getFinalColor's rayDepth; -1 = the driver's own (1,0,0,1,1) */
-    int32_t  samples;         /* spp / lens samples / blur steps; <=0 = the driver's default (64,100,7) */
+    int32_t  ray_depth;       /* getFinalColor's rayDepth; -1 = the driver's own (1,0,0,1,1; COMPOSED: 0 with
+                                 samples or lens_samples on, as the reference's sampling drivers pass, else 1) */
+    int32_t  samples;         /* spp / lens samples / blur steps; <=0 = the driver's default (64,100,7; COMPOSED: 1) */
     float    aperture;        /* DoF, default 0.1                               */
     float    focal_length;    /* DoF, default 2.0                               */
     int32_t  shadow_samples;  /* sampleSize,   src/light.cpp:14   (50)          */
@@ -211,7 +227,11 @@ typedef struct rtx_render_params {
     int32_t  tile_size;       /* square tile edge in pixels, 0 = default (32)   */
     int32_t  tile_rank, tile_world;
     rtx_camera prev_camera;   /* motion blur: camera of the previous call       */
-    int32_t  reserved[8];
+    /* RTX_DRIVER_COMPOSED only (ignored by the other drivers); <= 0 counts as 1 */
+    int32_t  lens_samples;    /* lens positions per pixel                       */
+    int32_t  time_steps;      /* poses of the exposure per pixel                */
+    int32_t  transparency;    /* != 0: the transparency chain on every camera sample's ray */
+    int32_t  reserved[5];
 } rtx_render_params;
 
 typedef struct rtx_stats {
@@ -227,9 +247,11 @@ typedef struct rtx_stats {
                                  device: camera rays of 8x8 blocks that cannot see the scene's
                                  bounds are counted (the reference makes and tests them) but never
                                  made, and a light sample behind the surface needs no ray */
-    uint64_t layer_overflows; /* RTX_DRIVER_TRANSPARENCY: camera rays that met more than 16
-                                 translucent surfaces; the 17th was taken as opaque, so their pixels
-                                 differ from the reference's unbounded recursion */
+    uint64_t layer_overflows; /* transparency chains (RTX_DRIVER_TRANSPARENCY, RTX_DRIVER_COMPOSED) deeper than 16
+                                 translucent surfaces: the first 16 layers are folded innermost first exactly as
+                                 src/transparency.cpp:6-20 does, the deeper ones are summed front to back -- the
+                                 same colour up to fp32 rounding of the order of summation; a chain has no
+                                 bound, as in the reference */
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;   /* device-resident scene, reference-counted */

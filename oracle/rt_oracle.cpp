@@ -1170,6 +1170,15 @@ Camera toCamera(const rtx_camera* c, int W, int H)
 
 // --------------------------------------------------------------- drivers ----
 int defaultDepth(int driver) { return (driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF) ? 0 : 1; }
+// the sample of the drivers' motion-blur pose (src/render.cpp:224-235): the current camera moved on by w pose changes
+Camera poseAt(const Camera& cam, const Camera& prev, float w)
+{
+    Camera c2 = cam;
+    c2.lookAt = cam.lookAt + w * (cam.lookAt - prev.lookAt);
+    c2.euler = cam.euler + w * (cam.euler - prev.euler);
+    c2.dist = cam.dist + w * (cam.dist - prev.dist);
+    return c2;
+}
 
 // src/render.cpp:69-253; one call renders one pixel
 V3 renderPixel(Ctx& cx, const Camera& cam, const Camera& prev, const rtx_render_params& rp, int x, int y)
@@ -1248,6 +1257,52 @@ V3 renderPixel(Ctx& cx, const Camera& cam, const Camera& prev, const rtx_render_
             col = col + finalColor(cx, c2.generate(ndcX, ndcY), depth, kPrimary);
         }
         return col / float(n);
+    }
+    case RTX_DRIVER_COMPOSED: {
+        // The four sampling drivers in one frame (the reference's router, src/main.cpp:50-63, runs one of
+        // them; the combination is this build's own, stated in include/rtx.h): time step x lens sample x
+        // pixel jitter, the pieces and their draws in that order per sample, a dimension of size 1 off.
+        const int J = std::max(rp.samples, 1), L = std::max(rp.lens_samples, 1), T = std::max(rp.time_steps, 1), S = T * L * J;
+        const uint64_t per = uint64_t(T > 1 ? 1 : 0) + uint64_t(J > 1 ? 2 : 0) + uint64_t(L > 1 ? 3 : 0);
+        const int d = rp.ray_depth >= 0 ? rp.ray_depth : ((J > 1 || L > 1) ? 0 : 1);
+        const float aperture = rp.aperture > 0.f ? rp.aperture : 0.1f;
+        const float focal = rp.focal_length > 0.f ? rp.focal_length : 2.0f;
+        Minstd rng = Minstd::at(pixelIndex * per * uint64_t(S));
+        V3 col = mk(0, 0, 0);
+        for (int s = 0; s < S; s++) {
+            const int t = s / (L * J);
+            cx.rng.start(uint32_t(pixelIndex), uint32_t(s));
+            Camera c2 = cam;
+            if (T > 1) { // src/render.cpp:224-235
+                const float jitter = rng.uniform(0.f, 1.f);
+                const float lerp = jitter + float(t);
+                c2 = poseAt(cam, prev, lerp / float(T));
+            }
+            float qx = ndcX, qy = ndcY;
+            if (J > 1) { // src/render.cpp:170-174
+                const float jx = rng.uniform(0.f, 1.f);
+                const float jy = rng.uniform(0.f, 1.f);
+                qx = float(float(x) + jx) / float(W) * 2.0f - 1.0f;
+                qy = float(float(y) + jy) / float(H) * 2.0f - 1.0f;
+            }
+            Ray r = c2.generate(qx, qy);
+            if (L > 1) { // src/dof.cpp:9-39
+                const V3 focalPoint = r.o + focal * r.d;
+                const float sx = rng.uniform(-aperture / 2, aperture / 2);
+                const float sy = rng.uniform(-aperture / 2, aperture / 2);
+                const float sz = rng.uniform(-aperture / 2, aperture / 2);
+                r.o = r.o + mk(sx, sy, sz);
+                r.d = normalize(focalPoint - r.o);
+            }
+            const V3 value = rp.transparency ? transparencyColor(cx, r, d) : finalColor(cx, r, d, kPrimary);
+            if (S == 1)
+                return value;
+            col = col + value;
+        }
+        if (J == 1 && L == 1)
+            return col / float(S); // src/render.cpp:249
+        const float inv = 1.0f / float(S); // src/render.cpp:178, :122
+        return col * mk(inv, inv, inv);
     }
     default:
         return mk(0, 0, 0);

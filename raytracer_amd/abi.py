@@ -12,7 +12,7 @@ i32, u32, f32 = C.c_int32, C.c_uint32, C.c_float
 RTX_TRI_NONE = -1
 RTX_MAX_MIP_LEVELS = 16
 
-DRIVER_PLAIN, DRIVER_MRAYS, DRIVER_DOF, DRIVER_TRANSPARENCY, DRIVER_MOTION_BLUR = range(5)
+DRIVER_PLAIN, DRIVER_MRAYS, DRIVER_DOF, DRIVER_TRANSPARENCY, DRIVER_MOTION_BLUR, DRIVER_COMPOSED = range(6)
 LIGHT_POINT, LIGHT_SEGMENT, LIGHT_PARALLELOGRAM = range(3)
 ENV_CYLINDRICAL, ENV_SPHERICAL = range(2)
 
@@ -36,7 +36,7 @@ class RenderParams(C.Structure):
     _fields_ = [("width", i32), ("height", i32), ("driver", i32), ("ray_depth", i32), ("samples", i32),
                 ("aperture", f32), ("focal_length", f32), ("shadow_samples", i32), ("glossy_rays", i32),
                 ("seed", u32), ("tile_size", i32), ("tile_rank", i32), ("tile_world", i32),
-                ("prev_camera", Camera), ("reserved", i32 * 8)]
+                ("prev_camera", Camera), ("lens_samples", i32), ("time_steps", i32), ("transparency", i32), ("reserved", i32 * 5)]
 
 
 class Stats(C.Structure):

@@ -45,7 +45,7 @@ namespace {
 #define RTX_LIGHT_WAVES 4
 #endif
 constexpr int kMaxDepth = 8;    // frames of the reflection recursion kept per lane
-constexpr int kMaxLayers = 16;  // transparent layers along one camera ray
+constexpr int kMaxLayers = 16;  // transparent layers along one camera ray that are kept one by one (deeper ones are summed front to back)
 
 // ------------------------------------------------------------ statistics ----
 enum { S_PRIMARY = 0, S_SHADOW, S_BOUNCE, S_BOX, S_TRI, S_SHADED, S_TRACED, S_OVERFLOW, S_COUNT };
@@ -56,7 +56,7 @@ enum { S_PRIMARY = 0, S_SHADOW, S_BOUNCE, S_BOX, S_TRI, S_SHADED, S_TRACED, S_OV
 struct LaneCounters {
     uint32_t primary = 0, shadow = 0, bounce = 0, shaded = 0;
     uint32_t traced = 0;   // counted rays that did walk the scene (not: rays of blocks that cannot see it, light samples behind the surface)
-    uint32_t overflow = 0; // camera samples whose transparency chain was cut at kMaxLayers
+    uint32_t overflow = 0; // camera samples whose transparency chain went deeper than kMaxLayers
     TraceCounters tc { 0, 0 };
     RTX_DEV void countPrimary(bool lane) { primary += __popcll(laneMask(lane)); }
     RTX_DEV void countShadow(bool lane) { shadow += __popcll(laneMask(lane)); }
@@ -330,6 +330,12 @@ struct RenderArgs {
     int32_t W, H, driver, depth, samples, shadowSamples, glossyRays;
     uint32_t seed;
     float aperture, focal;
+    // RTX_DRIVER_COMPOSED: samples = timeSteps * lensSamples * jitterSamples, sample s = (t * lensSamples + l) *
+    // jitterSamples + j; drawsPerSample of the sequential engine per sample (time 1, pixel 2, lens 3, each only
+    // when its dimension is on)
+    int32_t lensSamples, jitterSamples, timeSteps, drawsPerSample;
+    int32_t transparency; // the transparency chain runs on every camera sample's ray (src/transparency.cpp:6-20)
+    int32_t normalise;    // how a pixel's samples become its colour: NORM_*
     // interleaved-tile partition
     int32_t tileSize, tileRank, tileWorld, tilesX, tilesY, tilesMine;
     int32_t compact; // 1: write this rank's tiles back to back, 0: Screen layout
@@ -519,6 +525,19 @@ struct Frame { // one suspended getFinalColor call (src/render.cpp:16-66)
     int32_t traced; // the fan's rays have been traced ahead (fanT / fanK / fanSphere / fanSphereN hold their hits)
 };
 
+// A pixel from its samples: the one sample as it is (src/render.cpp:80-83), the sum in sample order times
+// 1 / count (src/render.cpp:178, :122), the sum divided by the count (src/render.cpp:249)
+enum Normalise { NORM_SINGLE = 0, NORM_RECIPROCAL = 1, NORM_DIVIDE = 2 };
+RTX_DEV V3 normalisePixel(V3 accum, int how, int samples)
+{
+    if (how == NORM_RECIPROCAL) {
+        const float inv = 1.0f / float(samples);
+        return accum * mk(inv, inv, inv);
+    }
+    if (how == NORM_DIVIDE)
+        return accum / float(samples);
+    return accum;
+}
 enum PathState { PS_DONE = 0, PS_RADIANCE = 1, PS_SHADOW = 2, PS_AREA = 3, PS_ENV = 4, PS_FAN = 5 };
 constexpr int kFanMax = 8; // glossy fans of up to this many rays are traced by the wave's lanes side by side
 enum Phase { PH_NONE = -1, PH_NEXT_LIGHT, PH_ENV, PH_AFTER_LIGHTS, PH_NEXT_CHILD, PH_RETURN };
@@ -546,7 +565,7 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
 {
     const DScene& sc = A.sc;
     const rtx_features& f = A.f;
-    const bool transparencyDriver = FULL && A.driver == RTX_DRIVER_TRANSPARENCY;
+    const bool transparencyDriver = FULL && A.transparency != 0;
 
     int state = active ? PS_RADIANCE : PS_DONE;
     V3 ro = camO, rd = camD; // ray in flight
@@ -580,12 +599,18 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     const int fanGroup = min(max(A.glossyRays, 1), kFanMax), fanPerRound = 64 / fanGroup;
     const int fanSlot = lane0() / fanGroup, fanChild = lane0() - fanSlot * fanGroup;
     // transparency chain (src/transparency.cpp:6-20): alpha and colour of each
-    // layer in front of the last one
+    // layer in front of the last one.  The reference folds them innermost first,
+    // value = alpha_i * colour_i + (1 - alpha_i) * value; the first kMaxLayers layers are kept and
+    // folded exactly so.  A chain has no bound there, so layers deeper than that are summed front to
+    // back as they come (tailSum += tailThrough * alpha * colour, tailThrough *= 1 - alpha): the same
+    // value up to the rounding of a different order of summation, under a factor
+    // prod (1 - alpha_i) of the kMaxLayers layers in front.
     float layerAlpha[FULL ? kMaxLayers : 1];
     V3 layerColor[FULL ? kMaxLayers : 1];
     int nLayers = 0;
     bool lastLayer = true;
-    V3 nextLayerO = mk(0, 0, 0);
+    float pendingAlpha = 1.0f, tailThrough = 1.0f;
+    V3 nextLayerO = mk(0, 0, 0), tailSum = mk(0, 0, 0);
 
     // shadow query in flight: search limit, early-stop distance and whether the
     // light sample is behind the surface (then no traversal is needed); see
@@ -836,10 +861,10 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
             // result of a radiance ray = body of getFinalColor
             if (transparencyDriver && level == 0) {
                 const float alpha = (any && hit.material >= 0) ? sc.mats[hit.material].transparency : 1.0f;
-                lastLayer = !any || alpha == 1.0f || nLayers >= kMaxLayers;
-                overflowPending = any && alpha != 1.0f && nLayers >= kMaxLayers; // (the chain is cut here: reported in rtx_stats)
+                lastLayer = !any || alpha == 1.0f;
+                overflowPending = !lastLayer && nLayers == kMaxLayers; // (counted once per camera sample: reported in rtx_stats)
                 if (!lastLayer) {
-                    layerAlpha[nLayers] = alpha;
+                    pendingAlpha = alpha;
                     const float adv = float(double(t) + 1e-6);
                     nextLayerO = ro + mk(adv, adv, adv) * rd;
                 }
@@ -1057,7 +1082,14 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                     continue;
                 }
                 if (transparencyDriver && !lastLayer) {
-                    layerColor[nLayers++] = value;
+                    if (nLayers < kMaxLayers) {
+                        layerAlpha[nLayers] = pendingAlpha;
+                        layerColor[nLayers] = value;
+                    } else {
+                        tailSum = tailSum + (tailThrough * pendingAlpha) * value;
+                        tailThrough = tailThrough * (1.0f - pendingAlpha);
+                    }
+                    nLayers++;
                     ro = nextLayerO;
                     rd = camD;
                     state = PS_RADIANCE;
@@ -1065,8 +1097,10 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
                     break;
                 }
                 if (transparencyDriver) {
+                    if (nLayers > kMaxLayers)
+                        value = tailSum + tailThrough * value;
                     // transparency * front + (1 - transparency) * behind, innermost first
-                    for (int i = nLayers - 1; i >= 0; i--)
+                    for (int i = min(nLayers, kMaxLayers) - 1; i >= 0; i--)
                         value = layerAlpha[i] * layerColor[i] + (1.0f - layerAlpha[i]) * value;
                 }
                 result = value;
@@ -1562,7 +1596,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
     const int lane = threadIdx.x & 63;
     const int slot = lane / A.lanesPerPixel, sub = lane % A.lanesPerPixel;
     const bool laneUsed = slot < A.pixelsPerUnit;
-    const bool averaging = A.driver == RTX_DRIVER_MRAYS || A.driver == RTX_DRIVER_DOF || A.driver == RTX_DRIVER_MOTION_BLUR;
+    const bool averaging = A.normalise != NORM_SINGLE;
     // the lane that ends up holding its pixel's sum and stores it
     const bool writer = laneUsed && sub == A.lanesPerPixel - 1;
 
@@ -1692,6 +1726,45 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
                             d = rotate(qw, qv, dirCam);
                         }
                         break;
+                    case RTX_DRIVER_COMPOSED: {
+                        // time step x lens sample x pixel jitter (see rtx_driver): the drivers' own pieces,
+                        // their draws in the order time, pixel, lens
+                        uint64_t rng = driverRngState(A, x, y, pixelIndex, sample, A.drawsPerSample);
+                        float w = 0.f;
+                        if (A.timeSteps > 1) {
+                            const int step = sample / (A.lensSamples * A.jitterSamples);
+                            const float jitter = minstdUniform(rng, 0.f, 1.f);
+                            w = (jitter + float(step)) / float(A.timeSteps);
+                        }
+                        float qx = ndcX, qy = ndcY;
+                        if (A.jitterSamples > 1) {
+                            const float jx = minstdUniform(rng, 0.f, 1.f);
+                            const float jy = minstdUniform(rng, 0.f, 1.f);
+                            qx = float(float(x) + jx) / float(A.W) * 2.0f - 1.0f;
+                            qy = float(float(y) + jy) / float(A.H) * 2.0f - 1.0f;
+                        }
+                        if (BLUR && A.timeSteps > 1) { // (the host sends such frames to the kernels that carry the poses' trigonometry)
+                            const V3 lookAt = mk(A.cam.look_at) + w * (mk(A.cam.look_at) - mk(A.prev.look_at));
+                            const V3 euler = mk(A.cam.euler) + w * (mk(A.cam.euler) - mk(A.prev.euler));
+                            const float dist = A.cam.distance + w * (A.cam.distance - A.prev.distance);
+                            float qw;
+                            V3 qv;
+                            quatFromEuler(euler, qw, qv);
+                            const V3 dirCam = normalize(mk(-qx * A.cam.half_width, qy * A.cam.half_height, 1.0f));
+                            o = lookAt + rotate(qw, qv, mk(0, 0, -dist));
+                            d = rotate(qw, qv, dirCam);
+                        } else {
+                            cameraRay(A.cam, qx, qy, o, d);
+                        }
+                        if (A.lensSamples > 1) {
+                            const V3 focalPoint = o + A.focal * d;
+                            const float sx = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
+                            const float sy = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
+                            const float sz = minstdUniform(rng, -A.aperture / 2, A.aperture / 2);
+                            o = o + mk(sx, sy, sz);
+                            d = normalize(focalPoint - o);
+                        }
+                    } break;
                     default:
                         cameraRay(A.cam, ndcX, ndcY, o, d);
                         break;
@@ -1765,16 +1838,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
         if (MODE != 4 && MODE != 9 && writer && storeIndex != 0xffffffffu) {
             {
                 const uint32_t outIndex = storeIndex;
-                V3 px = accum;
-                if (A.driver == RTX_DRIVER_MRAYS) {
-                    const float inv = 1.0f / (float(A.samples) * 1.0f);
-                    px = accum * mk(inv, inv, inv);
-                } else if (A.driver == RTX_DRIVER_DOF) {
-                    const float inv = 1.0f / float(A.samples);
-                    px = accum * mk(inv, inv, inv);
-                } else if (A.driver == RTX_DRIVER_MOTION_BLUR) {
-                    px = accum / float(A.samples);
-                }
+                const V3 px = normalisePixel(accum, A.normalise, A.samples);
                 float* dst = A.out + size_t(outIndex) * 3;
                 storeRgb(dst, px);
             }
@@ -2094,7 +2158,7 @@ struct ResolveArgs {
     Deferred defer;
     float* out;
     uint32_t nPixels;   // output pixels (the frame, or this rank's tile buffer)
-    int32_t samples, driver;
+    int32_t samples, normalise;
 };
 // getFinalColor's arithmetic replayed from a sample's tape (src/render.cpp:16-66)
 RTX_DEV V3 resolveTape(const Deferred& D, uint32_t head)
@@ -2161,22 +2225,13 @@ __global__ void __launch_bounds__(256) resolveKernel(ResolveArgs R)
     if (heads[0] == kHeadUntouched)
         return; // another rank's pixel, or a block that cannot see the scene (written black by the walk)
     // the samples of a pixel are added one after another onto a zero (src/render.cpp:168-178)
-    const bool averaging = R.driver == RTX_DRIVER_MRAYS || R.driver == RTX_DRIVER_DOF || R.driver == RTX_DRIVER_MOTION_BLUR;
+    const bool averaging = R.normalise != NORM_SINGLE;
     V3 accum = mk(0, 0, 0);
     for (int s = 0; averaging && s < R.samples; s++)
         accum = accum + resolveTape(D, heads[s]);
-    V3 px = accum;
-    if (R.driver == RTX_DRIVER_MRAYS) {
-        const float inv = 1.0f / (float(R.samples) * 1.0f);
-        px = accum * mk(inv, inv, inv);
-    } else if (R.driver == RTX_DRIVER_DOF) {
-        const float inv = 1.0f / float(R.samples);
-        px = accum * mk(inv, inv, inv);
-    } else if (R.driver == RTX_DRIVER_MOTION_BLUR) {
-        px = accum / float(R.samples);
-    } else {
+    V3 px = normalisePixel(accum, R.normalise, R.samples);
+    if (!averaging)
         px = resolveTape(D, heads[0]); // (not a sum: the one sample as it is, -0 included)
-    }
     float* dst = R.out + size_t(i) * 3;
     storeRgb(dst, px);
 }
@@ -2983,7 +3038,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     if (int rc = tileGeom(p, g))
         return rc;
     const int driver = p->driver;
-    if (driver < RTX_DRIVER_PLAIN || driver > RTX_DRIVER_MOTION_BLUR) {
+    if (driver < RTX_DRIVER_PLAIN || driver > RTX_DRIVER_COMPOSED) {
         setErr("unknown driver %d", driver);
         return RTX_ERR_INVALID;
     }
@@ -3008,13 +3063,25 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.W = p->width;
     A.H = p->height;
     A.driver = driver;
-    const bool sampled = driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF || driver == RTX_DRIVER_MOTION_BLUR;
-    A.depth = p->ray_depth >= 0 ? p->ray_depth : ((driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF) ? 0 : 1);
+    // the composed driver's dimensions (1 = off); the single drivers are the composition with one dimension on
+    const bool composed = driver == RTX_DRIVER_COMPOSED;
+    const int64_t nJitter = composed ? std::max(p->samples, 1) : 1, nLens = composed ? std::max(p->lens_samples, 1) : 1, nTime = composed ? std::max(p->time_steps, 1) : 1;
+    if (nJitter * nLens * nTime > (int64_t(1) << 20)) {
+        setErr("composed driver: %lld x %lld x %lld samples per pixel exceed the limit of 2^20", (long long)nTime, (long long)nLens, (long long)nJitter);
+        return RTX_ERR_LIMIT;
+    }
+    A.jitterSamples = int32_t(nJitter), A.lensSamples = int32_t(nLens), A.timeSteps = int32_t(nTime);
+    A.drawsPerSample = (nTime > 1 ? 1 : 0) + (nJitter > 1 ? 2 : 0) + (nLens > 1 ? 3 : 0);
+    A.transparency = (driver == RTX_DRIVER_TRANSPARENCY || (composed && p->transparency != 0)) ? 1 : 0;
+    const bool lensOn = driver == RTX_DRIVER_DOF || nLens > 1, posesOn = driver == RTX_DRIVER_MOTION_BLUR || nTime > 1;
+    const bool sampled = driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF || driver == RTX_DRIVER_MOTION_BLUR || (composed && A.drawsPerSample > 0);
+    A.normalise = !sampled ? NORM_SINGLE : (driver == RTX_DRIVER_MOTION_BLUR || (composed && nJitter == 1 && nLens == 1)) ? NORM_DIVIDE : NORM_RECIPROCAL;
+    A.depth = p->ray_depth >= 0 ? p->ray_depth : ((driver == RTX_DRIVER_MRAYS || driver == RTX_DRIVER_DOF || (composed && (nJitter > 1 || nLens > 1))) ? 0 : 1);
     if (A.depth > kMaxDepth) {
         setErr("ray_depth %d exceeds the limit of %d", A.depth, kMaxDepth);
         return RTX_ERR_LIMIT;
     }
-    A.samples = !sampled ? 1 : (p->samples > 0 ? p->samples : (driver == RTX_DRIVER_MRAYS ? 64 : driver == RTX_DRIVER_DOF ? 100 : 7));
+    A.samples = !sampled ? 1 : composed ? int32_t(nJitter * nLens * nTime) : (p->samples > 0 ? p->samples : (driver == RTX_DRIVER_MRAYS ? 64 : driver == RTX_DRIVER_DOF ? 100 : 7));
     A.shadowSamples = p->shadow_samples > 0 ? p->shadow_samples : 50;
     if (int rc = checkEnvLight(scene, f, A.shadowSamples))
         return rc;
@@ -3053,7 +3120,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         }
     const uint64_t outPixels = compact ? uint64_t(g.tilesMine) * g.ts * g.ts : uint64_t(A.W) * uint64_t(A.H);
     const bool deferred = !fixedArena && f->enable_shading && f->enable_soft_shadow && scene->hasAreaLight && !f->enable_environment_mapping
-        && driver != RTX_DRIVER_TRANSPARENCY && nCounting >= 1 && nCounting <= uint32_t(kMaxDeferLights) && outPixels * uint64_t(A.samples) < 0xffffffffull
+        && !A.transparency && nCounting >= 1 && nCounting <= uint32_t(kMaxDeferLights) && outPixels * uint64_t(A.samples) < 0xffffffffull
         && g.tilesMine > 0 && !getenv("RTX_NO_DEFER");
     if (deferred && f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1) {
         // A deferred frame's walk is bound by its deepest camera sample, whose tree of up to
@@ -3097,7 +3164,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
 
     // the full kernel carries the reflection / transparency / area-light /
     // texture / environment machinery; the lean one is enough otherwise
-    const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || driver == RTX_DRIVER_TRANSPARENCY;
+    const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || A.transparency;
     // (glossy fans are traced side by side where a wave holds few pixels, i.e. under area
     // lights: with a full wave of paths the lanes' own traversals already run side by side)
     const bool fans = f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1 && A.glossyRays <= kFanMax
@@ -3114,7 +3181,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // 81) and loses beyond (35 against 18 ms at 116), and up to some 200 pixels where triangles
     // are large on the screen (headline scene: 1.29 against 1.45 ms at 200))
     double swayPixels = 0.0;
-    if (driver == RTX_DRIVER_MOTION_BLUR) {
+    if (posesOn) {
         double dl = 0.0, turn = 0.0;
         for (int i = 0; i < 3; i++) {
             const double dLook = double(cam->look_at[i]) - double(p->prev_camera.look_at[i]);
@@ -3127,17 +3194,17 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         if (!std::isfinite(swayPixels))
             swayPixels = INFINITY;
     }
-    const bool bundles = driver != RTX_DRIVER_DOF && (driver != RTX_DRIVER_MOTION_BLUR || swayPixels <= (sparse ? 256.0 : 64.0));
+    const bool bundles = !lensOn && (!posesOn || swayPixels <= (sparse ? 256.0 : 64.0));
     const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : bundles && (A.lanesPerPixel >= 2 || sparse);
     // (the motion-blur driver's lean kernels carry the per-sample camera's trigonometry: modes 6 / 7)
-    const int mode = !full ? (driver == RTX_DRIVER_MOTION_BLUR ? (together ? 6 : 7) : (together ? 0 : 5)) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
+    const int mode = !full ? (posesOn ? (together ? 6 : 7) : (together ? 0 : 5)) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
     // Mode 8 = mode 0 with every ray of the frame read from an origin's frame: the camera rays
     // of these drivers all start at the camera position, the shadow rays at their point light.
     // (The fixed-workspace entry point must not allocate and goes without: same arithmetic,
     // same pixels.)
     A.camFrame = OriginFrame { nullptr, nullptr };
     int launchMode = mode;
-    if (mode == 0 && !fixedArena && !originFramesOff() && (driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS) && f->enable_accel_structure && scene->d.nTris > 0) {
+    if (mode == 0 && !fixedArena && !originFramesOff() && (driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS || (composed && !lensOn && !posesOn)) && f->enable_accel_structure && scene->d.nTris > 0) {
         bool lightsHaveFrames = scene->lightTypes.size() <= size_t(kLightFrames);
         for (size_t li = 0; li < scene->lightTypes.size() && lightsHaveFrames; li++) // (other kinds do not count in the lean kernels)
             lightsHaveFrames = scene->lightTypes[li] != RTX_LIGHT_POINT || scene->d.lightFrame[li].nodes != nullptr;
@@ -3196,12 +3263,12 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.cullX1 = A.cullY1 = 0;
     A.nCutRects = 0;
     // (depth of field: sample origins lie within half the diagonal of the aperture cube of the camera position)
-    const double lens = driver == RTX_DRIVER_DOF ? 0.5 * std::sqrt(3.0) * double(A.aperture) * 1.0001 : 0.0, lensFocal = double(A.focal);
+    const double lens = lensOn ? 0.5 * std::sqrt(3.0) * double(A.aperture) * 1.0001 : 0.0, lensFocal = double(A.focal);
     // (motion blur: the samples' poses run from the current one to one full pose change beyond
     // it; the rectangle is taken from the pose halfway, grown by how far the others stray from it)
     rtx_camera cullCam = *cam;
     double sway = 0.0, turn = 0.0;
-    if (driver == RTX_DRIVER_MOTION_BLUR) {
+    if (posesOn) {
         double dl = 0, e[3], q[4];
         for (int i = 0; i < 3; i++) {
             const double dLook = double(cam->look_at[i]) - double(p->prev_camera.look_at[i]), dEuler = double(cam->euler[i]) - double(p->prev_camera.euler[i]);
@@ -3271,7 +3338,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     A.jumpS = a->jump + 2 * a->jumpMaxDim;
     A.jumpSamples = 0;
     if (sampled) {
-        const int d = driver == RTX_DRIVER_MRAYS ? 2 : driver == RTX_DRIVER_DOF ? 3 : 1;
+        const int d = composed ? A.drawsPerSample : driver == RTX_DRIVER_MRAYS ? 2 : driver == RTX_DRIVER_DOF ? 3 : 1;
         const int ns = std::min(A.samples, a->jumpMaxSamples);
         A.jumpSamples = ns;
         if (a->jumpW != A.W || a->jumpH != A.H || a->jumpS != A.samples || a->jumpD != d) {
@@ -3399,7 +3466,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         R.out = dOut;
         R.nPixels = uint32_t(outPixels);
         R.samples = A.samples;
-        R.driver = driver;
+        R.normalise = A.normalise;
         hipLaunchKernelGGL(resolveKernel, dim3((R.nPixels + 255u) / 256u), dim3(256), 0, c->stream, R);
         // A frame whose pools ran over (the flag says so on the device) is rendered again by the
         // one-kernel path, in the walk's units; that launch returns at once otherwise.

@@ -401,4 +401,51 @@ void renderRayTracingMotionBlur(const Scene& scene, const Trackball& camera, con
 }
 void resetMotionBlur() { g_blur.rendered = false; }
 
+void renderRayTracingComposed(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, const ComposedSampling& how)
+{
+    // (the exposure's poses extrapolate from the pose change since the previous call, exactly as in
+    // renderRayTracingMotionBlur, whose state this shares: its first call renders a still frame)
+    rtx_render_params p = baseParams(RTX_DRIVER_COMPOSED);
+    p.samples = how.jitterSamples;
+    p.lens_samples = how.lensSamples;
+    p.time_steps = how.timeSteps;
+    p.transparency = how.transparency ? 1 : 0;
+    p.aperture = how.aperture;
+    p.focal_length = how.focalLength;
+    p.ray_depth = how.rayDepth;
+    if (how.timeSteps > 1) {
+        if (!g_blur.rendered) {
+            p.time_steps = 1;
+            g_blur.rendered = true;
+        } else {
+            p.prev_camera = g_blur.start;
+        }
+        g_blur.start = camera.deviceCamera();
+    }
+    (void)scene;
+    renderFrame(bvh, camera, screen, features, p);
+}
+void renderRayTracingRouter(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features)
+{
+    const int on = int(features.extra.enableDepthOfField) + int(features.extra.enableMotionBlur) + int(features.extra.enableTransparency) + int(features.extra.enableMultipleRaysPerPixel);
+    if (on >= 2) {
+        ComposedSampling how;
+        how.jitterSamples = features.extra.enableMultipleRaysPerPixel ? 64 : 1; // the drivers' default counts (src/render.h:22-26)
+        how.lensSamples = features.extra.enableDepthOfField ? 100 : 1;
+        how.timeSteps = features.extra.enableMotionBlur ? 7 : 1;
+        how.transparency = features.extra.enableTransparency;
+        renderRayTracingComposed(scene, camera, bvh, screen, features, how);
+    } else if (features.extra.enableDepthOfField) {
+        renderRayTracingDepthOfField(scene, camera, bvh, screen, features);
+    } else if (features.extra.enableMotionBlur) {
+        renderRayTracingMotionBlur(scene, camera, bvh, screen, features);
+    } else if (features.extra.enableTransparency) {
+        renderRayTracingTransparency(scene, camera, bvh, screen, features);
+    } else if (features.extra.enableMultipleRaysPerPixel) {
+        renderRayTracingMRaysPerPixel(scene, camera, bvh, screen, features);
+    } else {
+        renderRayTracing(scene, camera, bvh, screen, features);
+    }
+}
+
 } // namespace rt

@@ -154,6 +154,24 @@ void renderRayTracingMRaysPerPixel(const Scene& scene, const Trackball& camera, 
 void renderRayTracingMotionBlur(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, int steps = 7);
 // Forget the remembered motion-blur camera (the reference never does).
 void resetMotionBlur();
+// The four sampling drivers above in ONE frame: per pixel timeSteps x lensSamples x jitterSamples camera
+// samples (a count of 1 switches its dimension off), the transparency chain on every sample's ray if asked
+// for.  The reference's router (src/main.cpp:50-63) picks one driver even when several of
+// enableDepthOfField / enableMotionBlur / enableTransparency / enableMultipleRaysPerPixel are set; this is
+// the frame in which all that are set take effect.  Each driver above is this one with the other
+// dimensions off, bit for bit (see RTX_DRIVER_COMPOSED in rtx.h).  Shares renderRayTracingMotionBlur's
+// remembered camera: with timeSteps > 1 the first call renders the exposure as a single pose.
+struct ComposedSampling {
+    int jitterSamples = 1, lensSamples = 1, timeSteps = 1;
+    bool transparency = false;
+    float aperture = 0.1f, focalLength = 2.0f; // src/render.h:22
+    int rayDepth = -1;                         // -1: 0 with jitter or lens samples on (as the reference's sampling drivers pass), else 1
+};
+void renderRayTracingComposed(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, const ComposedSampling& how);
+// renderRayTracingRouter of src/main.cpp:50-63 with one change: two or more of the four switches set
+// render the composed frame (the drivers' default counts: 64 jitter samples, 100 lens samples, 7 poses)
+// instead of the first driver in the reference's priority order.
+void renderRayTracingRouter(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features);
 
 // src/render.h:29: the colour carried by one ray.  One device launch per call;
 // getFinalColorBatch shades n rays at once (ray i samples lights / glossy

@@ -207,3 +207,70 @@ def test_get_final_color_batches_bit_exact(golden_shade):
         ok = ~np.isnan(want)
         assert np.array_equal(bits(got)[ok], bits(want)[ok]), name
         assert np.nansum(want) > 0
+
+
+# The composed driver (RTX_DRIVER_COMPOSED) has no reference frame: the reference's router runs one of its
+# four sampling drivers at a time (src/main.cpp:50-63).  It is pinned through its reductions instead: with
+# all dimensions but one off it must be that dimension's driver, bit for bit -- and those drivers are held
+# to the reference's own frames above.
+_MOVED = dict(look_at=(0, 0, 0.3), rotation_degrees=(24, 17, 0), distance=3.2)
+COMPOSED_REDUCTIONS = [
+    ("pixel jitter alone = MRaysPerPixel", "monkey", dict(cases.BASE), dict(samples=5), dict(driver=abi.DRIVER_MRAYS, samples=5)),
+    ("lens samples alone = DepthOfField", "monkey", dict(cases.BASE), dict(lens_samples=6, aperture=0.15, focal_length=2.5), dict(driver=abi.DRIVER_DOF, samples=6, aperture=0.15, focal_length=2.5)),
+    ("time steps alone = MotionBlur", "monkey", dict(cases.BASE, recursive=1), dict(time_steps=4, prev=_MOVED), dict(driver=abi.DRIVER_MOTION_BLUR, samples=4, prev=_MOVED)),
+    ("transparency alone = Transparency", "transparency", dict(cases.BASE, recursive=1), dict(transparency=1), dict(driver=abi.DRIVER_TRANSPARENCY)),
+    ("nothing on = the plain driver", "cornell", dict(cases.BASE, recursive=1), dict(), dict()),
+    ("explicit depth, glossy", "cornell", dict(cases.BASE, recursive=1, glossy_reflection=1), dict(samples=2, ray_depth=2, glossy_rays=3), dict(driver=abi.DRIVER_MRAYS, samples=2, ray_depth=2, glossy_rays=3)),
+]
+
+
+def composed_pair(scene_name, features, composed, single, width=40, height=30):
+    """(scene, features, camera, composed parameters, the single driver's parameters)"""
+    scene = cases.load_scene(scene_name)
+    f = abi.features(**features)
+    cam = cases.make_camera()
+
+    def params(kw, driver):
+        kw = dict(kw)
+        prev = kw.pop("prev", None)
+        rp = cases.make_params(width, height, **dict(dict(driver=driver), **kw))
+        if prev is not None:
+            rp.prev_camera = cases.make_camera(**prev)
+        return rp
+    return scene, f, cam, params(composed, abi.DRIVER_COMPOSED), params(single, abi.DRIVER_PLAIN)
+
+
+@pytest.mark.parametrize("name,scene_name,features,composed,single", COMPOSED_REDUCTIONS, ids=[c[0] for c in COMPOSED_REDUCTIONS])
+def test_composed_driver_reduces_to_each_driver(name, scene_name, features, composed, single):
+    scene, f, cam, rp_composed, rp_single = composed_pair(scene_name, features, composed, single)
+    orc = OracleEngine(scene, f)
+    a = orc.render(cam, f, rp_composed)
+    rays_a = orc.counters[:3].copy()
+    b = orc.render(cam, f, rp_single)
+    assert np.array_equal(rays_a, orc.counters[:3]), name
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+    orc.close()
+
+
+def test_composed_driver_sample_order_and_counts():
+    """All four at once: time x lens x jitter samples per pixel, the chain on every sample's ray.  What can
+    be said without a reference frame: the ray count is what the dimensions multiply to (plus the layers
+    behind translucent surfaces), and a frame whose samples all coincide -- two time steps between
+    identical poses, lens samples through an aperture that rounds to nothing -- is NOT the plain frame's
+    bits (the lens construction renormalises the direction) but stays within rounding of it."""
+    scene = cases.load_scene("transparency")
+    f = abi.features(**dict(cases.BASE, recursive=1))
+    cam = cases.make_camera()
+    orc = OracleEngine(scene, f)
+    rp = cases.make_params(24, 18, driver=abi.DRIVER_COMPOSED, samples=2, lens_samples=3, time_steps=2, transparency=1, aperture=0.05)
+    rp.prev_camera = cases.make_camera(look_at=(0, 0.1, 0.2))
+    a = orc.render(cam, f, rp)
+    primary = int(orc.counters[0])
+    assert primary >= 24 * 18 * 12 and np.isfinite(a).all() and a.max() > 0
+    plain = orc.render(cam, f, cases.make_params(24, 18, driver=abi.DRIVER_TRANSPARENCY))
+    still = cases.make_params(24, 18, driver=abi.DRIVER_COMPOSED, lens_samples=2, time_steps=2, transparency=1, aperture=1e-30, ray_depth=1)
+    still.prev_camera = cam
+    b = orc.render(cam, f, still)
+    assert np.array_equal(np.isnan(b), np.isnan(plain)) and np.isnan(plain).any()   # (the mirror's NaN pixels, src/render.cpp:31-41)
+    assert np.nanmax(np.abs(b - plain)) < 1e-4
+    orc.close()
