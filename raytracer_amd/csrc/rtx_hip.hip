@@ -19,6 +19,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "rtx.h"
@@ -2601,6 +2602,30 @@ int ensureCameraFrame(DeviceCtx* c, const rtx_scene* s, const float* pos, Origin
     return RTX_OK;
 }
 
+// Calls f with the kernels' stack size as a compile-time constant.  A development build
+// (-DRTX_DEV_BUILD: tools/dev_build.sh) instantiates only the 16-entry kernels without test counters,
+// an eighth of the library, for experiments on trees of at most 16 levels; pickStack refuses deeper ones there.
+template <class F>
+void withStack(int stack, F f)
+{
+#ifdef RTX_DEV_BUILD
+    (void)stack;
+    f(std::integral_constant<int, 16> {});
+#else
+    switch (stack) {
+    case 16: f(std::integral_constant<int, 16> {}); break;
+    case 24: f(std::integral_constant<int, 24> {}); break;
+    case 32: f(std::integral_constant<int, 32> {}); break;
+    default: f(std::integral_constant<int, 64> {}); break;
+    }
+#endif
+}
+#ifdef RTX_DEV_BUILD
+#define RTX_IF_COUNT(count) if (false)
+#else
+#define RTX_IF_COUNT(count) if (count)
+#endif
+
 int pickStack(int numLevels)
 {
     // nearer-child-first depth-first traversal holds at most one entry per level
@@ -2608,6 +2633,9 @@ int pickStack(int numLevels)
         numLevels = std::max(numLevels, atoi(e));
     if (numLevels <= 16)
         return 16;
+#ifdef RTX_DEV_BUILD
+    return -1;
+#endif
     if (numLevels <= 24)
         return 24;
     if (numLevels <= 32)
@@ -2656,12 +2684,13 @@ WorkQueue makeQueue(const DeviceCtx* c, const Arena* a, uint32_t nUnits)
 template <int STACK>
 int launchTrace(DeviceCtx* c, const TraceArgs& A, bool count)
 {
-    const void* k = count ? (const void*)traceKernel<STACK, true> : (const void*)traceKernel<STACK, false>;
-    const int grid = std::max(1, std::min<int>(gridFor(c, k), int((A.work.nChunks + 3) / 4)));
-    if (count)
+    RTX_IF_COUNT(count) {
+        const int grid = std::max(1, std::min<int>(gridFor(c, (const void*)traceKernel<STACK, true>), int((A.work.nChunks + 3) / 4)));
         hipLaunchKernelGGL((traceKernel<STACK, true>), dim3(grid), dim3(kBlock), 0, c->stream, A);
-    else
+    } else {
+        const int grid = std::max(1, std::min<int>(gridFor(c, (const void*)traceKernel<STACK, false>), int((A.work.nChunks + 3) / 4)));
         hipLaunchKernelGGL((traceKernel<STACK, false>), dim3(grid), dim3(kBlock), 0, c->stream, A);
+    }
     return RTX_OK;
 }
 
@@ -2689,7 +2718,7 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode, size_t
     case 1: RTX_LAUNCH(CNT, 1) break;                                                                             \
     default: RTX_LAUNCH(CNT, 0) break;                                                                            \
     }
-    if (count)
+    RTX_IF_COUNT(count)
         RTX_LAUNCH_MODES(true)
     else
         RTX_LAUNCH_MODES(false)
@@ -2784,12 +2813,7 @@ int traceImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, rtx_hit* d
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
         const bool count = wantCounters();
-        switch (stack) {
-        case 16: launchTrace<16>(c, A, count); break;
-        case 24: launchTrace<24>(c, A, count); break;
-        case 32: launchTrace<32>(c, A, count); break;
-        default: launchTrace<64>(c, A, count); break;
-        }
+        withStack(stack, [&](auto S) { launchTrace<decltype(S)::value>(c, A, count); });
         HIP_TRY(hipGetLastError());
     }
     if (stats)
@@ -3020,7 +3044,7 @@ int ensureDeferPools(DeviceCtx* c, size_t headWords, uint32_t nCounting)
 template <int STACK>
 void launchLights(DeviceCtx* c, const LightArgs& L, bool count)
 {
-    if (count) {
+    RTX_IF_COUNT(count) {
         const int grid = gridFor(c, (const void*)lightKernel<STACK, true>);
         hipLaunchKernelGGL((lightKernel<STACK, true>), dim3(grid), dim3(kBlock), 0, c->stream, L);
     } else {
@@ -3392,12 +3416,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         HIP_TRY(hipMemsetAsync(a->tickets, 0, kTicketBytes + kStatBytes, c->stream)); // the statistics follow the tickets
     const bool count = wantCounters();
     auto launch = [&](const RenderArgs& R, int m, size_t lds) {
-        switch (stack) {
-        case 16: launchRender<16>(c, R, count, m, lds); break;
-        case 24: launchRender<24>(c, R, count, m, lds); break;
-        case 32: launchRender<32>(c, R, count, m, lds); break;
-        default: launchRender<64>(c, R, count, m, lds); break;
-        }
+        withStack(stack, [&](auto S) { launchRender<decltype(S)::value>(c, R, count, m, lds); });
     };
     if (deferred && A.work.nUnits) {
         const Deferred& D = A.defer;
@@ -3450,12 +3469,7 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
             L.work.aheadFrom = 0;
             L.stats = a->stats;
             hipLaunchKernelGGL(planLightsKernel, dim3(1), dim3(64), 0, c->stream, D, uint32_t(std::min(L.nS, 64)), control + kDeferTicketWords, control + kDeferTicketWords + kDeferUnitWords);
-            switch (stack) {
-            case 16: launchLights<16>(c, L, count); break;
-            case 24: launchLights<24>(c, L, count); break;
-            case 32: launchLights<32>(c, L, count); break;
-            default: launchLights<64>(c, L, count); break;
-            }
+            withStack(stack, [&](auto S) { launchLights<decltype(S)::value>(c, L, count); });
             HIP_TRY(hipGetLastError());
             if (type != RTX_LIGHT_POINT)
                 offset += (type == RTX_LIGHT_SEGMENT ? 1u : 2u) * uint32_t(A.shadowSamples);
@@ -3503,9 +3517,9 @@ void launchShade(DeviceCtx* c, const ShadeArgs& S, bool count, bool envLight)
         const int grid = std::max(1, std::min<int>(gridFor(c, k), int((S.R.work.nChunks + 3) / 4)));           \
         hipLaunchKernelGGL((shadeKernel<STACK, CNT, ENVV>), dim3(grid), dim3(kBlock), 0, c->stream, S);        \
     }
-    if (count && envLight)
+    RTX_IF_COUNT(count && envLight)
         RTX_LAUNCH(true, true)
-    else if (count)
+    else RTX_IF_COUNT(count)
         RTX_LAUNCH(true, false)
     else if (envLight)
         RTX_LAUNCH(false, true)
@@ -3556,12 +3570,7 @@ int shadeImpl(const rtx_scene* scene, const rtx_ray* dRays, size_t n, const rtx_
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (n) {
         const bool count = wantCounters();
-        switch (stack) {
-        case 16: launchShade<16>(c, S, count, f->enable_soft_shadow && f->enable_environment_mapping); break;
-        case 24: launchShade<24>(c, S, count, f->enable_soft_shadow && f->enable_environment_mapping); break;
-        case 32: launchShade<32>(c, S, count, f->enable_soft_shadow && f->enable_environment_mapping); break;
-        default: launchShade<64>(c, S, count, f->enable_soft_shadow && f->enable_environment_mapping); break;
-        }
+        withStack(stack, [&](auto K) { launchShade<decltype(K)::value>(c, S, count, f->enable_soft_shadow && f->enable_environment_mapping); });
         HIP_TRY(hipGetLastError());
     }
     if (stats)
