@@ -414,7 +414,19 @@ __global__ void __launch_bounds__(256) wideRecordsKernel(BuildBuffers B, Outputs
             o[24 + slot] = __int_as_float(used ? refs[k] : INT32_MIN);
         }
         o[28] = __int_as_float(n);
-        o[29] = o[30] = o[31] = 0.f;
+        // the triangle counts of leaf children, slot by slot, 16 bits each (traverseFrontier)
+        uint32_t counts[2] = { 0u, 0u };
+        for (int slot = 0; slot < n; slot++) {
+            const Child& kid = kids[order[slot]];
+            if (kid.leaf) {
+                counts[slot >> 1] |= (min(kid.count, 0xffffu) & 0xffffu) << (16 * (slot & 1));
+                if (kid.count > kFrontierMaxLeaf && oct == 0)
+                    atomicOr(&B.scalars[9], 1u); // (a leaf no frontier item can count: that walk is not used on this scene)
+            }
+        }
+        o[29] = __uint_as_float(counts[0]);
+        o[30] = __uint_as_float(counts[1]);
+        o[31] = 0.f;
         float4* dst = O.waveNodes + (size_t(oct) * O.nWide + B.wideIndex[i]) * 8;
         for (int q = 0; q < 8; q++)
             dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);

@@ -89,6 +89,7 @@ struct DScene {
     int32_t nWaveNodes;
     int32_t waveRoot;        // 0 (the root node), ~first triangle when the root is a leaf
     int32_t boxesNested;     // every child box lies within its parent's box, the root's children within the root box
+    int32_t frontierOk;      // the four-wide records carry their leaf children's triangle counts and every index fits a frontier item (traverseFrontier)
     const float4* attrs;     // 4 x float4 per rtx_tri_attr
     const int32_t* idOrder;  // leaf-order record index of triangle id i (brute-force path)
     const rtx_material* mats;
@@ -392,6 +393,7 @@ struct LaneStack {
 struct TraceCounters {
     uint32_t boxTests, triTests;
 #ifdef RTX_PROBE
+    uint32_t frontierRounds = 0, frontierEntries = 0; // traverseFrontier: rounds of this wave, live entries this lane handled
     uint32_t outer = 0, inner = 0; // this lane's trips through the traversal loop and the leaf loop
     uint32_t waveOuter = 0, waveInner = 0; // trips in which this lane was the lowest active one: summed over the wave, the wave's trips
 #endif
@@ -796,6 +798,200 @@ RTX_DEV void traverseWaveTogether(const DScene& sc, LaneStack<STACK>& st, bool l
     }
     if (anyLane(in && !finiteInv))
         traverseBvhWave<STACK, COUNT, EARLY, BOX_LITERAL>(sc, st, o, d, inv, in && !finiteInv, 0u, t, bestK, tc, tStop);
+}
+
+// ------------------------------------------------------ frontier traversal --
+// Closest hits of a FEW rays (the five rays of a glossy fan) with the WHOLE wave at work on them.
+// Walked one node at a time, such a bundle is a chain of dependent fetches with most of the wave's
+// lanes idle, and the walk of a deep glossy sample is hundreds of such bundles one after the other
+// (their order is forced: the draws are numbered along the walk) -- the frame waits for that chain.
+// Here every ray gets a group of G = 64 / rays lanes and a stack of its own in LDS, kept nearest
+// on top as in any depth-first walk; but each round the group pops the TOP G entries at once, a
+// lane each: a node entry tests the ray against the node's four child boxes (the reference's visit
+// rule on that ray, in the ray's own octant copy, whose children are stored nearest first) and
+// pushes the children entered, a leaf as a run of triangles; a triangle entry tests two triangles,
+// lowers the ray's best hit with an LDS atomic and hands the rest of its run on in up to three
+// parts.  Entries whose key lies behind the best hit known when they are popped are dropped, as in
+// the other walks.  The fetches of a round are in flight together, so a ray's walk takes about as
+// many round trips to memory as its path to the hit is deep: what a depth-first walk spends
+// backing out of subtrees happens beside it.  Every ray still tests only boxes and triangles it
+// could test walking alone; what differs is the ORDER, hence, as for the other walks, only which
+// of two triangles met at exactly the same distance is reported (the one earlier in leaf order
+// here).  The stacks live in the wave's columns of the traversal stacks' LDS, which no other walk
+// uses meanwhile.  Returns false, with nothing decided, when a stack would outgrow its share: the
+// caller then walks the rays the old way.
+constexpr uint32_t kFrontierWords = 2u * uint32_t(kLdsStack) * 64u;   // LDS words of one wave's stacks
+constexpr uint32_t kItemTri = 0x80000000u, kItemIndexMask = (1u << 25) - 1u; // triangle entry: kind | (run - 1) << 25 | first triangle
+constexpr uint32_t kFrontierMaxIndex = kItemIndexMask, kFrontierMaxLeaf = 64u;
+// The visit rule of one child for one ray in the ray's mirrored frame (childVisit's arithmetic, per lane)
+RTX_DEV bool childTestMirrored(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im, float limit, float& key)
+{
+    const float dlx = lox - om.x, dly = loy - om.y, dlz = loz - om.z;
+    const float dhx = hix - om.x, dhy = hiy - om.y, dhz = hiz - om.z;
+    const float t0x = dlx * im.x, t0y = dly * im.y, t0z = dlz * im.z;
+    const float t1x = dhx * im.x, t1y = dhy * im.y, t1z = dhz * im.z;
+    const float first = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
+    const float second = fminf(fminf(t1x, t1y), t1z);
+    const bool miss = first > second;
+    key = first <= 0.0f ? second : first;
+    const bool in = fmaxf(fmaxf(dlx, dly), dlz) <= 0.0f && fminf(fminf(dhx, dhy), dhz) >= 0.0f;
+    key = in ? 0.0f : key;
+    return in || (!miss && !(limit < key));
+}
+// Rays in lanes 0 .. nRays - 1 (`lane`: the ray is to be traced; nRays wave-uniform, 1 .. 64).
+// `best`: 64 words of LDS of this wave.  Must be called by all lanes of the wave together; t,
+// bestK as in traverseBvh.
+template <int STACK, bool COUNT>
+RTX_DEV bool traverseFrontier(const DScene& sc, LaneStack<STACK>& st, unsigned long long* best, uint32_t nRays, bool lane, V3 o, V3 d, float& t, int& bestK, TraceCounters& tc)
+{
+    static_assert(LaneStack<STACK>::kLds == kLdsStack, "the stacks take the traversal stacks' 2 x kLdsStack rows");
+    bestK = -1;
+    const uint32_t me = threadIdx.x & 63u;
+    int32_t* const q = st.refs + (st.tid & ~63);
+    auto word = [](uint32_t w) { return (w >> 6) * uint32_t(kBlock) + (w & 63u); }; // the wave's w-th word
+    const uint32_t G = 64u / nRays, cap = (kFrontierWords / nRays) >> 1;              // lanes and stack entries per ray
+    const uint32_t g = min(me / G, nRays - 1u), j = me - g * G;                        // this lane's ray and place in its group
+    const bool grouped = me < nRays * G;
+    // the ray's own part: root box, octant, mirrored frame
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool finiteInv = fabsf(inv.x) < __builtin_inff() && fabsf(inv.y) < __builtin_inff() && fabsf(inv.z) < __builtin_inff();
+    bool in = lane && me < nRays;
+    if (in) {
+        float key; // the root box, as in traverseBvh
+        if (COUNT)
+            tc.boxTests++;
+        in = slab(mk(sc.rootLo), mk(sc.rootHi), o, inv, t, key);
+    }
+    // (an axis-parallel ray takes the comparison-by-comparison test on the boxes as they are: octant 0's copy)
+    const uint32_t myOct = finiteInv ? ((inv.x < 0.f ? 1u : 0u) | (inv.y < 0.f ? 2u : 0u) | (inv.z < 0.f ? 4u : 0u)) : 0u;
+    const V3 myOm = finiteInv ? mk((myOct & 1u) ? -o.x : o.x, (myOct & 2u) ? -o.y : o.y, (myOct & 4u) ? -o.z : o.z) : o;
+    const V3 myIm = finiteInv ? mk(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z)) : inv;
+    best[me] = (static_cast<unsigned long long>(__float_as_uint(t)) << 32) | 0xffffffffull;
+    // the group's copy of its ray
+    const int src = int(g);
+    const V3 ro = mk(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
+    const V3 rd = mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
+    const V3 om = mk(__shfl(myOm.x, src, 64), __shfl(myOm.y, src, 64), __shfl(myOm.z, src, 64));
+    const V3 im = mk(__shfl(myIm.x, src, 64), __shfl(myIm.y, src, 64), __shfl(myIm.z, src, 64));
+    const bool rFinite = __shfl(int(finiteInv), src, 64) != 0;
+    const float4* const nodes = sc.waveNodes + size_t(uint32_t(__shfl(int(myOct), src, 64))) * size_t(uint32_t(sc.nWaveNodes)) * kWaveNodeQuads;
+    uint32_t sp = __shfl(int(in), src, 64) != 0 ? 1u : 0u; // entries on this group's stack (the same in all its lanes)
+    const uint32_t stackAt = g * 2u * cap;                   // its first word
+    if (grouped && j == 0u && sp) {
+        q[word(stackAt)] = 0;                                // key 0
+        q[word(stackAt + 1u)] = sc.waveRoot;
+    }
+    bool ok = true;
+    while (anyLane(grouped && sp != 0u)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t popped = min(G, sp);
+        const bool have = grouped && j < popped;
+        const uint32_t at = stackAt + 2u * (sp - popped + j);  // (lane 0 takes the farthest of the popped entries, the last lane the top)
+        const float entryKey = have ? __int_as_float(q[word(at)]) : 0.f;
+        const uint32_t entry = have ? uint32_t(q[word(at + 1u)]) : 0u;
+        const float limit = __uint_as_float(uint32_t(best[g] >> 32));
+        const bool live = have && !(limit < entryKey);
+        const bool isTri = (entry & kItemTri) != 0u;
+#ifdef RTX_PROBE
+        tc.frontierRounds++;
+        tc.frontierEntries += live ? 1u : 0u;
+#endif
+        // up to four entries to push, farthest first
+        float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
+        uint32_t e0 = 0u, e1 = 0u, e2 = 0u, e3 = 0u, n0 = 0u, n1 = 0u, n2 = 0u, n3 = 0u;
+        if (live && !isTri) {
+            const float4* p = nodes + size_t(entry) * kWaveNodeQuads;
+            const float4 XL = p[0], XH = p[1], YL = p[2], YH = p[3], ZL = p[4], ZH = p[5], R = p[6], M = p[7];
+            const int nChildren = __float_as_int(M.x);
+            const uint32_t c01 = __float_as_uint(M.y), c23 = __float_as_uint(M.z);
+            if (COUNT)
+                tc.boxTests += uint32_t(nChildren);
+            auto child = [&](int c, float lx, float ly, float lz, float hx, float hy, float hz, float r, uint32_t tris, float& key, uint32_t& e, uint32_t& n) {
+                const bool enter = rFinite ? childTestMirrored(lx, ly, lz, hx, hy, hz, om, im, limit, key)
+                                           : (c < nChildren && childTest(mk(lx, ly, lz), mk(hx, hy, hz), om, im, limit, key));
+                const int32_t ref = __float_as_int(r);
+                e = ref >= 0 ? uint32_t(ref) : (kItemTri | ((tris - 1u) << 25) | uint32_t(~ref));
+                n = enter ? 1u : 0u;
+            };
+            // (the children are stored nearest first: the nearest goes on last)
+            child(3, XL.w, YL.w, ZL.w, XH.w, YH.w, ZH.w, R.w, c23 >> 16, k0, e0, n0);
+            child(2, XL.z, YL.z, ZL.z, XH.z, YH.z, ZH.z, R.z, c23 & 0xffffu, k1, e1, n1);
+            child(1, XL.y, YL.y, ZL.y, XH.y, YH.y, ZH.y, R.y, c01 >> 16, k2, e2, n2);
+            child(0, XL.x, YL.x, ZL.x, XH.x, YH.x, ZH.x, R.x, c01 & 0xffffu, k3, e3, n3);
+        } else if (live) {
+            const uint32_t first = entry & kItemIndexMask, run = ((entry >> 25) & 63u) + 1u;
+            const float4* p = sc.tris + size_t(first) * 4;
+            const float4 X0 = p[0], Y0 = p[1], Z0 = p[2], W0 = p[3];
+            const bool two = run >= 2u;
+            const float4* p2 = p + (two ? 4 : 0);
+            const float4 X1 = p2[0], Y1 = p2[1], Z1 = p2[2], W1 = p2[3];
+            if (COUNT)
+                tc.triTests += two ? 2u : 1u;
+            float th;
+            float lim = limit;
+            if (triangleTestPacked(X0, Y0, Z0, W0.x, ro, rd, lim, th)) {
+                atomicMin(best + g, (static_cast<unsigned long long>(__float_as_uint(th)) << 32) | first);
+                lim = th;
+            }
+            if (two && triangleTestPacked(X1, Y1, Z1, W1.x, ro, rd, lim, th))
+                atomicMin(best + g, (static_cast<unsigned long long>(__float_as_uint(th)) << 32) | (first + 1u));
+            // the rest of the run, in up to three parts for as many lanes of the next round
+            if (run > 2u) {
+                const uint32_t rest = run - 2u, a = (rest + 2u) / 3u, b = (rest - a + 1u) / 2u, c = rest - a - b;
+                uint32_t from = first + 2u;
+                e0 = kItemTri | ((a - 1u) << 25) | from, n0 = 1u, k0 = entryKey;
+                from += a;
+                if (b) {
+                    e1 = kItemTri | ((b - 1u) << 25) | from, n1 = 1u, k1 = entryKey;
+                    from += b;
+                }
+                if (c)
+                    e2 = kItemTri | ((c - 1u) << 25) | from, n2 = 1u, k2 = entryKey;
+            }
+        }
+        // where this lane's entries go: behind those of the group's lanes before it (votes and population
+        // counts: no trip through the lanes' exchange network)
+        const uint64_t v0 = laneMask(n0 != 0u), v1 = laneMask(n1 != 0u), v2 = laneMask(n2 != 0u), v3 = laneMask(n3 != 0u);
+        const uint32_t mine = (n0 + n1) + (n2 + n3);
+        const uint64_t groupMask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (g * G);
+        const uint64_t beforeMe = groupMask & ((1ull << me) - 1ull);
+        const uint32_t beforeInGroup = uint32_t(__popcll(v0 & beforeMe) + __popcll(v1 & beforeMe)) + uint32_t(__popcll(v2 & beforeMe) + __popcll(v3 & beforeMe));
+        const uint32_t groupTotal = uint32_t(__popcll(v0 & groupMask) + __popcll(v1 & groupMask)) + uint32_t(__popcll(v2 & groupMask) + __popcll(v3 & groupMask));
+        const uint32_t newSp = sp - popped + groupTotal;
+        if (anyLane(grouped && newSp > cap)) {
+            ok = false;
+            break;
+        }
+        uint32_t to = stackAt + 2u * (sp - popped + beforeInGroup);
+        (void)mine;
+        if (n0) {
+            q[word(to)] = __float_as_int(k0);
+            q[word(to + 1u)] = int32_t(e0);
+            to += 2u;
+        }
+        if (n1) {
+            q[word(to)] = __float_as_int(k1);
+            q[word(to + 1u)] = int32_t(e1);
+            to += 2u;
+        }
+        if (n2) {
+            q[word(to)] = __float_as_int(k2);
+            q[word(to + 1u)] = int32_t(e2);
+            to += 2u;
+        }
+        if (n3) {
+            q[word(to)] = __float_as_int(k3);
+            q[word(to + 1u)] = int32_t(e3);
+        }
+        sp = grouped ? newSp : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned long long found = best[me];
+    if (ok && in && uint32_t(found) != 0xffffffffu) {
+        t = __uint_as_float(uint32_t(found >> 32));
+        bestK = int(uint32_t(found));
+    }
+    return ok;
 }
 
 // Brute-force path (features.enableAccelStructure == false),

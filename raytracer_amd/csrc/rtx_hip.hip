@@ -71,6 +71,27 @@ struct LaneCounters {
 // diagnostic build: per unit of the last frame (ticks, longest lane's loop trips, longest lane's leaf trips, sum of the lanes' loop trips)
 constexpr uint32_t kProbeUnits = 1u << 20;
 __device__ uint4 g_probe[kProbeUnits];
+// the walk of a deferred frame, per unit: ticks of the 100 MHz clock spent making rays, walking the tree, on hit
+// attributes, on the shading points' numbers (an atomic's round trip), on shading points / exchange / tape, on the
+// state machine's advance; then the iterations that served fans and the others
+struct WalkProbe {
+    uint32_t make, walk, attributes, numbers, records, advance, fanTrips, otherTrips;
+    uint32_t rounds, entries, pad0, pad1; // traverseFrontier: rounds, live entries handled (summed over the wave)
+};
+__device__ WalkProbe g_walkProbe[kProbeUnits];
+struct WalkLaps {
+    WalkProbe p {};
+    uint64_t last = wall_clock64();
+    RTX_DEV void lap(uint32_t& into)
+    {
+        const uint64_t now = wall_clock64();
+        into += uint32_t(now - last);
+        last = now;
+    }
+};
+#define RTX_LAP(field) laps.lap(laps.p.field)
+#else
+#define RTX_LAP(field)
 #endif
 
 RTX_DEV uint64_t waveSum(uint32_t v)
@@ -317,7 +338,8 @@ struct Deferred {
     uint32_t drawsPerPoint; // keyed draws one shading point's light loop consumes
     uint32_t fanLevels;    // > 0: glossy fans are traced side by side, their hits kept in LDS for this many levels
     uint32_t leafFans;     // the rays of a fan that ends the recursion are finished by the lanes that traced them
-    uint32_t fansTogether; // the rays of a fan walk the tree together (closestHitWave): pays when a wave serves one or two fans at a time
+    uint32_t frontier;     // the rays of the fans a wave serves at a time are walked by the whole wave, a group of lanes per ray (traverseFrontier)
+    uint32_t fansPerRound; // fans a wave serves per iteration at most (few, so that each ray's group has several lanes)
     uint2* primary;        // per (output pixel, sample): the camera ray's closest hit (t bits, triangle record or -1) from the camera pass; nullptr: the walk traces it
 };
 __host__ __device__ inline uint32_t* deferOverflow(const Deferred& D) { return D.counters + 2 * kPools * kPoolStride; }
@@ -1235,12 +1257,17 @@ struct WalkFrame { // one getFinalColor call whose children are being followed
     uint32_t rngBase;
     int32_t child, nChildren, traced;
 };
-// Hits of the glossy fans traced ahead, in LDS: entry (level, ray) of lane l at [(level * rays + ray) * kBlock + l]
+constexpr int32_t kNotFollowed = -2; // FanStore::k of a fan's ray whose direction fails the test of src/render.cpp:31-38
+// Hits of the glossy fans traced ahead, in LDS: entry (level, ray) of the workgroup's path `slot` at
+// [(level * rays + ray) * slots + slot].  Only the lanes that carry a camera sample hold fans (one lane of a wave
+// where a unit is one pixel), so the store has a slot per such lane, not per lane: a workgroup's share of LDS
+// then leaves the number of waves a CU holds to the kernel's registers.
 struct FanStore {
     float* t;
     int32_t* k;
-    int tid, rays; // rays: the fan size
-    RTX_DEV int at(int level, int ray) const { return (level * rays + ray) * kBlock + tid; }
+    int slot, slots, rays; // rays: the fan size
+    unsigned long long* best; // this wave's 64 words for traverseFrontier
+    RTX_DEV int at(int level, int ray) const { return (level * rays + ray) * slots + slot; }
 };
 
 // One camera sample's radiance rays, depth first; every lane of the wave calls this together.
@@ -1248,8 +1275,13 @@ struct FanStore {
 // its light loop will make (D.drawsPerPoint) and moves on.  Glossy fans of 2..kFanMax rays are
 // traced by the wave's lanes side by side as in tracePath (D.fanLevels > 0).
 template <int STACK, bool COUNT>
-RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V3 camO, V3 camD, bool active, uint32_t rngKey, uint32_t headIndex, LaneCounters& lc)
+RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V3 camO, V3 camD, bool active, uint32_t rngKey, uint32_t headIndex, LaneCounters& lc, uint32_t probeUnit = 0)
 {
+#ifdef RTX_PROBE
+    WalkLaps laps;
+#else
+    (void)probeUnit;
+#endif
     const DScene& sc = A.sc;
     const rtx_features& f = A.f;
     const Deferred& D = A.defer;
@@ -1270,12 +1302,27 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
         preT = __uint_as_float(seen.x);
         preK = int32_t(seen.y);
     }
-    const int fanGroup = min(max(A.glossyRays, 1), kFanMax), fanPerRound = 64 / fanGroup;
+    const int fanGroup = min(max(A.glossyRays, 1), kFanMax), fanPerRound = min(64 / fanGroup, int(D.fansPerRound));
     const int fanSlot = lane / fanGroup, fanChild = lane - fanSlot * fanGroup;
     TapeWriter tape;
     bool shadedPending = false;
+    uint32_t missedAhead = 0; // children settled in the advance loop (see there), still to be counted as bounce rays
+    // A frame's walk ends on its deepest samples, each a chain of fans traced one after the other by a wave that
+    // shares its SIMD with a wave of short units: once a sample has shown itself deep (a fan below the second
+    // level) its wave asks for the SIMD's issue slots first (measured: a 156-fan sample runs 35 us per fan beside
+    // another wave, 20 us alone).
+    bool raised = false;
 
     while (__any(state != PS_DONE)) {
+        RTX_LAP(advance);
+        if (!raised && anyLane(state == PS_FAN && level >= 3)) {
+            __builtin_amdgcn_s_setprio(3);
+            raised = true;
+        }
+        while (anyLane(missedAhead != 0u)) { // (the ray counters are the wave's: counted where the wave is converged)
+            lc.countBounce(missedAhead != 0u);
+            missedAhead -= missedAhead != 0u ? 1u : 0u;
+        }
         const uint64_t pendingFan = fans ? __ballot(state == PS_FAN) : 0ull;
         const bool coopFan = pendingFan != 0;
         lc.countShaded(shadedPending);
@@ -1336,9 +1383,18 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
         int bestK = -1, sphere = -1;
         V3 sphereN = mk(0, 0, 0);
         lc.countTraced(trace);
-        if (coopFan && D.fansTogether) // the rays of a fan leave one point in a narrow bundle
-            any = closestHitWave<STACK, COUNT, false, true>(sc, st, f, trace, qo, qd, t, bestK, sphere, sphereN, lc.tc);
-        else if (trace)
+        RTX_LAP(make);
+#ifdef RTX_PROBE
+        (coopFan ? laps.p.fanTrips : laps.p.otherTrips)++;
+#endif
+        bool walked = false;
+        if (coopFan && D.frontier) { // (no spheres in a frame whose fans are traced ahead)
+            walked = traverseFrontier<STACK, COUNT>(sc, st, fan.best, uint32_t(__popcll(served)) * uint32_t(fanGroup), trace, qo, qd, t, bestK, lc.tc);
+            any = trace && bestK >= 0;
+        }
+        // (otherwise, and for the rays that are not a fan's, lane by lane; the wave-shared walk is kept out of this
+        // kernel: a deep sample's wave runs alone on its SIMD and pays for every line of code it has to fetch)
+        if (!walked && trace)
             any = closestHit<STACK, COUNT>(sc, st, f, qo, qd, t, bestK, sphere, sphereN, lc.tc);
         if (!coopFan && state == PS_RADIANCE && preTraced) {
             t = preT;
@@ -1346,6 +1402,7 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
             any = bestK >= 0;
             preTraced = false;
         }
+        RTX_LAP(walk);
         const bool landed = !coopFan && state == PS_RADIANCE;
         // The rays of a fan that ends the recursion are whole getFinalColor calls by themselves
         // (hit or miss, the lights, no children): the lanes that traced them make their shading
@@ -1357,6 +1414,7 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
         else if (leafHit)
             hitAttributes(sc, f, qo, qd, t, bestK, sphere, sphereN, hit);
         lc.countBounce(coopFan && workerLeaf && trace);
+        RTX_LAP(attributes);
 
         // numbers for this iteration's shading points: one atomic per wave, the lanes in order
         const bool wantsPoint = (landed || leafHit) && any && f.enable_shading && !tape.failed;
@@ -1381,6 +1439,7 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
             }
         }
 
+        RTX_LAP(numbers);
         int phase = PH_NONE;
         if (coopFan) {
             if (anyLane(workerLeaf)) {
@@ -1418,7 +1477,7 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
             for (int j = 0; j < fanGroup; j++) {
                 const int from = min(k * fanGroup + j, 63);
                 const float jt = __shfl(t, from, 64);
-                const int jk = __shfl(bestK, from, 64);
+                const int jk = __shfl(trace ? bestK : kNotFollowed, from, 64);
                 const int jOutcome = __shfl(outcome, from, 64);
                 const uint32_t jPoint = uint32_t(__shfl(int(point), from, 64));
                 const int jFailed = __shfl(int(tape.failed), from, 64);
@@ -1521,6 +1580,7 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
             state = PS_DONE;
             phase = PH_NONE;
         }
+        RTX_LAP(records);
 
         bool launched = phase == PH_NONE;
         while (!launched) {
@@ -1529,6 +1589,25 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
                 phase = PH_RETURN;
                 while (F.child < F.nChildren) {
                     const int k = F.child++;
+                    if (F.traced) {
+                        // What the lanes that traced the fan found for this child (kNotFollowed: its direction
+                        // failed the test of src/render.cpp:31-38).  A child that is not followed, or that hit
+                        // nothing, is settled here without its direction being made again: a miss is a whole
+                        // getFinalColor call already -- black (src/render.cpp:61-64; a deferred frame has no
+                        // environment map), no draws, nothing below it -- and goes on the tape at once instead of
+                        // taking a turn of the loop above, which most of a frame's fans, whose rays leave the
+                        // mesh, would pay five times.
+                        preK = fan.k[fan.at(level - 1, k)];
+                        if (preK == kNotFollowed)
+                            continue;
+                        if (preK < 0) {
+                            tapeEmit(D, tape, TAPE_MISS, kNoPoint, mk(0, 0, 0), mk(0, 0, 0));
+                            missedAhead++;
+                            continue;
+                        }
+                        preT = fan.t[fan.at(level - 1, k)];
+                        preTraced = true;
+                    }
                     V3 dir = F.reflD;
                     if (f.enable_glossy_reflection) {
                         // returnGlossyRay, src/shading.cpp:67-88
@@ -1542,14 +1621,9 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
                     }
                     const float cosinus = dot(normalize(dir), F.nrm);
                     const float sinus = __builtin_sqrtf(1.0f - cosinus * cosinus);
-                    if (cosinus > 0.0f && sinus > 0.0f) {
+                    if (preTraced || (cosinus > 0.0f && sinus > 0.0f)) { // (a child traced ahead has passed the test)
                         ro = F.reflO;
                         rd = dir;
-                        if (F.traced) {
-                            preTraced = true;
-                            preT = fan.t[fan.at(level - 1, k)];
-                            preK = fan.k[fan.at(level - 1, k)];
-                        }
                         state = PS_RADIANCE;
                         launched = true;
                         break;
@@ -1573,8 +1647,22 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
         }
     }
     lc.countShaded(shadedPending);
+    while (anyLane(missedAhead != 0u)) {
+        lc.countBounce(missedAhead != 0u);
+        missedAhead -= missedAhead != 0u ? 1u : 0u;
+    }
     if (active && !tape.failed)
         D.heads[headIndex] = tape.head;
+    if (raised)
+        __builtin_amdgcn_s_setprio(0);
+#ifdef RTX_PROBE
+    RTX_LAP(advance);
+    laps.p.rounds = lc.tc.frontierRounds;
+    laps.p.entries = uint32_t(waveSum(lc.tc.frontierEntries));
+    lc.tc.frontierRounds = lc.tc.frontierEntries = 0;
+    if (lane == 0 && probeUnit < kProbeUnits)
+        g_walkProbe[probeUnit] = laps.p;
+#endif
 }
 
 // MODE 0: point lights + hard shadows only (tracePathLean); 1: the general path;
@@ -1590,6 +1678,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
     __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
     extern __shared__ int32_t sFan[]; // MODE 4: fanLevels * fan size * kBlock distances, then as many triangle records
+    __shared__ unsigned long long sBest[MODE == 4 ? kBlock : 1]; // MODE 4: traverseFrontier's best hit per ray
     if (A.runIf && __hip_atomic_load(A.runIf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
         return;
     LaneStack<STACK> st { sStack, reinterpret_cast<float*>(sStack + LaneStack<STACK>::kLds * kBlock), int(threadIdx.x), sWaveRefs + (threadIdx.x >> 6) * 2 * STACK };
@@ -1788,8 +1877,10 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
             }
             if (MODE == 4) {
                 const int fanRays = min(max(A.glossyRays, 1), kFanMax);
-                const FanStore fan { reinterpret_cast<float*>(sFan), sFan + A.defer.fanLevels * fanRays * kBlock, int(threadIdx.x), fanRays };
-                walkPath<STACK, COUNT>(A, st, fan, o, d, active, key, storeIndex * uint32_t(A.samples) + uint32_t(sample), lc);
+                const int pathLanes = A.pixelsPerUnit * A.lanesPerPixel, fanSlots = (kBlock / 64) * pathLanes; // (lanes of a wave that carry a sample)
+                const FanStore fan { reinterpret_cast<float*>(sFan), sFan + A.defer.fanLevels * fanRays * fanSlots, int(threadIdx.x >> 6) * pathLanes + min(lane, pathLanes - 1), fanSlots, fanRays,
+                    sBest + (threadIdx.x & ~63u) };
+                walkPath<STACK, COUNT>(A, st, fan, o, d, active, key, storeIndex * uint32_t(A.samples) + uint32_t(sample), lc, unit);
                 continue; // (the pixel is written by resolveKernel)
             }
             const V3 c = (MODE == 4 || MODE == 9) ? mk(0, 0, 0) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6 || MODE == 8, MODE == 8>(A, st, o, d, active, lc);
@@ -2166,52 +2257,75 @@ RTX_DEV V3 resolveTape(const Deferred& D, uint32_t head)
 {
     if (head == 0)
         return mk(0, 0, 0);
-    V3 Lo[kMaxDepth], ks[kMaxDepth], acc[kMaxDepth];
-    int32_t count[kMaxDepth];
+    // the calls whose children are being added up: the innermost in registers, the others on a stack
+    V3 stackLo[kMaxDepth], stackKs[kMaxDepth], stackAcc[kMaxDepth];
+    int32_t stackCount[kMaxDepth];
+    V3 Lo = mk(0, 0, 0), ks = mk(0, 0, 0), acc = mk(0, 0, 0);
+    int32_t count = 0;
     int level = 0;
     uint32_t at = (head - 1) * kTapeChunk;
-    // The replay of a deep sample (hundreds of entries) is a chain of dependent loads, entry
-    // after entry and each entry's lights after it: the next entry of the chunk is fetched while
-    // this one's lights are (a chunk's last entry is a link or the sample's end, so at + 1 stays
-    // inside the chunk whenever its value is used).
-    TapeEntry e = D.tape[at];
+    const uint32_t nPoints = D.pointsPerPool * uint32_t(kPools);
+    // The replay of a deep sample (hundreds of entries) is a chain of dependent loads when taken entry by
+    // entry, each entry's lights after it.  A chunk's entries lie side by side: all eight are fetched at
+    // once, then the lights' results of all of them, and only then are they replayed in order.  (Entries
+    // behind the sample's end are whatever an earlier frame left there: they are loaded, never used, and
+    // their points are looked at only when they lie inside the pools.)
     for (;;) {
-        if (e.op == TAPE_LINK) {
-            at = e.point * kTapeChunk;
-            e = D.tape[at];
-            continue;
-        }
-        const TapeEntry cur = e;
-        at++;
-        const bool ends = (level == 0 && cur.op != TAPE_OPEN) || (level == 1 && cur.op == TAPE_CLOSE); // (the sample's last entry: nothing of it lies behind)
-        if (!ends)
-            e = D.tape[at];
-        V3 value = mk(cur.a);
-        if (cur.op == TAPE_HIT || cur.op == TAPE_OPEN) {
+        TapeEntry e[kTapeChunk];
+        const TapeEntry* chunk = D.tape + at;
+#pragma unroll
+        for (uint32_t i = 0; i < kTapeChunk; i++)
+            e[i] = chunk[i];
+        V3 value[kTapeChunk];
+#pragma unroll
+        for (uint32_t i = 0; i < kTapeChunk; i++) {
+            value[i] = mk(e[i].a);
             // Lo: the lights in scene order (src/light.cpp:146-181)
-            if (cur.point != kNoPoint) {
-                const float* c = D.contrib + size_t(cur.point) * D.nCounting * 3;
+            if ((e[i].op == TAPE_HIT || e[i].op == TAPE_OPEN) && e[i].point < nPoints) {
+                const float* c = D.contrib + size_t(e[i].point) * D.nCounting * 3;
                 for (uint32_t j = 0; j < D.nCounting; j++)
-                    value = value + mk(c + 3 * j);
+                    value[i] = value[i] + mk(c + 3 * j);
             }
-            if (cur.op == TAPE_OPEN) {
-                Lo[level] = value;
-                ks[level] = mk(cur.ks);
-                acc[level] = mk(0, 0, 0);
-                count[level] = 0;
+        }
+        bool linked = false;
+#pragma unroll
+        for (uint32_t i = 0; i < kTapeChunk && !linked; i++) {
+            const uint32_t op = e[i].op;
+            if (op == TAPE_LINK) {
+                at = e[i].point * kTapeChunk;
+                linked = true;
+                break;
+            }
+            V3 v = value[i];
+            if (op == TAPE_OPEN) {
+                if (level > 0) {
+                    stackLo[level - 1] = Lo, stackKs[level - 1] = ks, stackAcc[level - 1] = acc;
+                    stackCount[level - 1] = count;
+                }
+                Lo = v;
+                ks = mk(e[i].ks);
+                acc = mk(0, 0, 0);
+                count = 0;
                 level++;
                 continue;
             }
-        } else if (cur.op == TAPE_CLOSE) {
-            // color *= 1/count (0 * inf = NaN when no child was followed), Lo + color * ks
-            level--;
-            const V3 color = acc[level] * (1.0f / float(count[level]));
-            value = Lo[level] + color * ks[level];
+            if (op == TAPE_CLOSE) {
+                // color *= 1/count (0 * inf = NaN when no child was followed), Lo + color * ks
+                const V3 color = acc * (1.0f / float(count));
+                v = Lo + color * ks;
+                level--;
+                if (level > 0) {
+                    Lo = stackLo[level - 1], ks = stackKs[level - 1], acc = stackAcc[level - 1];
+                    count = stackCount[level - 1];
+                }
+            }
+            if (level == 0)
+                return v;
+            acc = acc + v;
+            count++;
         }
-        if (level == 0)
-            return value;
-        acc[level - 1] = acc[level - 1] + value;
-        count[level - 1]++;
+        if (!linked)
+            return mk(0, 0, 0); // (a chunk without a link or an end: not written by the walk)
     }
 }
 __global__ void __launch_bounds__(256) resolveKernel(ResolveArgs R)
@@ -2621,7 +2735,7 @@ void withStack(int stack, F f)
 #endif
 }
 #ifdef RTX_DEV_BUILD
-#define RTX_IF_COUNT(count) if (false)
+#define RTX_IF_COUNT(count) if constexpr (false)
 #else
 #define RTX_IF_COUNT(count) if (count)
 #endif
@@ -3259,9 +3373,14 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         // (deeper fans, and scenes with spheres, whose hits are not triangle records: ray by ray)
         A.defer.fanLevels = 0;
         A.defer.leafFans = getenv("RTX_NO_LEAF_FANS") ? 0u : 1u; // (diagnostic switch)
-        A.defer.fansTogether = A.pixelsPerUnit * A.lanesPerPixel <= 2 ? 1u : 0u;
+        A.defer.frontier = (f->enable_accel_structure && scene->d.frontierOk && scene->d.waveRoot >= 0 && !getenv("RTX_NO_FRONTIER")) ? 1u : 0u;
+        // (few fans at a time, so that each ray's group has three or more lanes: measured with 8 pixels per
+        // wave at depth 2, 4 fans per iteration 4.98 ms against 5.9 ms with all 12)
+        A.defer.fansPerRound = A.defer.frontier ? 4 : 64;
+        if (const char* e = getenv("RTX_FANS_PER_ROUND")) // diagnostic
+            A.defer.fansPerRound = uint32_t(std::max(1, atoi(e)));
         if (f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1 && A.glossyRays <= kFanMax && scene->d.nSpheres == 0 && !getenv("RTX_NO_FANS")) {
-            const size_t perLevel = size_t(A.glossyRays) * kBlock * 8;
+            const size_t perLevel = size_t(A.glossyRays) * size_t(kBlock / 64) * size_t(A.pixelsPerUnit * A.lanesPerPixel) * 8;
             A.defer.fanLevels = uint32_t(std::min<size_t>(size_t(A.depth), (64 * 1024) / perLevel));
             walkLds = size_t(A.defer.fanLevels) * perLevel;
         }
@@ -3429,7 +3548,8 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         // -- the same query per ray, so the same hits -- and the walk picks them up.  (Measured on
         // the glossy depth 4 frame: 14.1 -> 12.9 ms per frame with two frames in flight, 17.7 ->
         // 17.9 ms alone; with eight pixels per wave, depth 2, it cost 7 % and is not taken.)
-        if (scene->d.nSpheres == 0 && A.pixelsPerUnit * A.lanesPerPixel <= 2 && A.pixelsPerUnit < mostPixelsPerUnit && !getenv("RTX_NO_CAMERA_PASS")) {
+        const int cameraPassUpTo = getenv("RTX_CAMERA_PASS_MAX") ? atoi(getenv("RTX_CAMERA_PASS_MAX")) : 2; // diagnostic
+        if (scene->d.nSpheres == 0 && A.pixelsPerUnit * A.lanesPerPixel <= cameraPassUpTo && A.pixelsPerUnit < mostPixelsPerUnit && !getenv("RTX_NO_CAMERA_PASS")) {
             A.defer.primary = reinterpret_cast<uint2*>(c->defer.heads + ((c->defer.headWords + 1) & ~size_t(1)));
             RenderArgs Cm = A;
             Cm.pixelsPerUnit = mostPixelsPerUnit;
@@ -3444,6 +3564,11 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemsetAsync(a->tickets, 0, kTicketBytes, c->stream)); // the work queue starts over for the walk
         }
+        // The walk's long units run for milliseconds (a deep glossy sample's fans one after the other): a wave
+        // that claimed its next chunk ahead would sit on it that long while other waves idle (measured: units
+        // of 156 fans early in the sequence began 4 ms into an 8 ms walk).  Only the cheap region's chunks,
+        // whose round trip is what a unit costs, are claimed ahead.
+        A.work.aheadFrom = getenv("RTX_CLAIM_AHEAD_FROM") ? A.work.aheadFrom : uint32_t(kRegions - 1);
         launch(A, 4, walkLds);
         HIP_TRY(hipGetLastError());
         uint32_t slot = 0, offset = 0;
@@ -4038,9 +4163,11 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     // inner children, in eight mirrored copies with the children sorted nearest first.
     struct Wide {
         int32_t ref[4];   // >= 0: binary node to be merged next, < 0: leaf reference of the flat tree; INT32_MIN: unused
+        int32_t cnt[4];   // triangles of a leaf child
         float lo[4][3], hi[4][3];
         int n;
     };
+    bool frontierOk = d->n_tris <= kFrontierMaxIndex && d->root_ref >= 0;
     std::vector<Wide> wide;
     int waveStackNeed = 0;
     if (d->root_ref >= 0) {
@@ -4050,8 +4177,17 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
             const rtx_node& top = d->nodes[binaryOf[at]];
             Wide w;
             w.n = 0;
-            auto add = [&](int32_t ref, const float* lo, const float* hi) {
+            auto add = [&](int32_t ref, int32_t cnt, const float* lo, const float* hi) {
                 w.ref[w.n] = ref;
+                w.cnt[w.n] = ref < 0 ? cnt : 0;
+                if (ref < 0 && frontierOk) {
+                    // (the other walks find a leaf's end by its last triangle's flag; the frontier walk goes by
+                    // the description's count, which must say the same)
+                    const uint64_t k = uint32_t(~ref);
+                    frontierOk = cnt >= 1 && uint32_t(cnt) <= kFrontierMaxLeaf && k + uint64_t(cnt) <= d->n_tris;
+                    for (int64_t j = 0; frontierOk && j < cnt; j++)
+                        frontierOk = ((d->tris[k + uint64_t(j)].flags & RTX_TRI_LAST_IN_LEAF) != 0) == (j == cnt - 1);
+                }
                 std::memcpy(w.lo[w.n], lo, 12);
                 std::memcpy(w.hi[w.n], hi, 12);
                 w.n++;
@@ -4060,10 +4196,10 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
                 const int32_t ref = side ? top.ref1 : top.ref0;
                 if (ref >= 0) {
                     const rtx_node& mid = d->nodes[ref];
-                    add(mid.ref0, mid.lo0, mid.hi0);
-                    add(mid.ref1, mid.lo1, mid.hi1);
+                    add(mid.ref0, mid.cnt0, mid.lo0, mid.hi0);
+                    add(mid.ref1, mid.cnt1, mid.lo1, mid.hi1);
                 } else {
-                    add(ref, side ? top.lo1 : top.lo0, side ? top.hi1 : top.hi0);
+                    add(ref, side ? top.cnt1 : top.cnt0, side ? top.lo1 : top.lo0, side ? top.hi1 : top.hi0);
                 }
             }
             for (int c = 0; c < w.n; c++)
@@ -4116,6 +4252,11 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
                 std::memcpy(o + 24 + slot, &ref, 4);
             }
             std::memcpy(o + 28, &w.n, 4); // number of children
+            // the triangle counts of leaf children, slot by slot, 16 bits each (traverseFrontier)
+            uint32_t counts[2] = { 0u, 0u };
+            for (int slot = 0; slot < w.n; slot++)
+                counts[slot >> 1] |= (uint32_t(w.cnt[order[slot]]) & 0xffffu) << (16 * (slot & 1));
+            std::memcpy(o + 29, counts, 8);
         }
     for (uint32_t i = 0; i < d->n_tris; i++) {
         const rtx_tri& a = d->tris[i];
@@ -4152,6 +4293,7 @@ rtx_scene* rtx_scene_create(const rtx_scene_desc* d)
     s->d.tris = reinterpret_cast<const float4*>(tris);
     s->d.attrs = reinterpret_cast<const float4*>(attrs);
     s->d.boxesNested = boxesNested ? 1 : 0;
+    s->d.frontierOk = frontierOk ? 1 : 0;
     s->d.nWaveNodes = int32_t(nWide);
     s->d.waveRoot = d->root_ref >= 0 ? 0 : (emptyTree ? kEmptyRoot : ~int32_t(uint32_t(~d->root_ref)));
     s->d.waveNodes = reinterpret_cast<const float4*>(dWaveNodes);
@@ -4368,6 +4510,7 @@ rtx_scene* rtx_scene_build_device(const rtx_scene_desc* d)
     O.attrs = static_cast<rtx_tri_attr*>(keep(size_t(n) * sizeof(rtx_tri_attr)));
     O.idOrder = static_cast<int32_t*>(keep(size_t(n) * 4));
     float rootBox[6] = {}, cut[1 + kMaxCutBoxes * 6] = {};
+    uint32_t bigLeaf = 1; // (set by the records' kernel when a leaf holds more triangles than a frontier item counts)
     if (ok) {
         // (the padding record is read -- never used -- by the pair fetch and copied into origin frames: zero, as rtx_scene_create leaves it)
         e = hipMemsetAsync(reinterpret_cast<unsigned char*>(O.waveTris) + size_t(n) * 96, 0, 96, stream);
@@ -4381,6 +4524,7 @@ rtx_scene* rtx_scene_build_device(const rtx_scene_desc* d)
         e = hipMemcpyAsync(rootBox, B.nodeLo, 12, hipMemcpyDeviceToHost, stream);
         e = e ? e : hipMemcpyAsync(rootBox + 3, B.nodeHi, 12, hipMemcpyDeviceToHost, stream);
         e = e ? e : hipMemcpyAsync(cut, dCut, sizeof(cut), hipMemcpyDeviceToHost, stream);
+        e = e ? e : hipMemcpyAsync(&bigLeaf, B.scalars + 9, sizeof(bigLeaf), hipMemcpyDeviceToHost, stream);
         e = e ? e : hipStreamSynchronize(stream);
         e = e ? e : hipGetLastError();
         ok = e == hipSuccess;
@@ -4408,6 +4552,7 @@ rtx_scene* rtx_scene_build_device(const rtx_scene_desc* d)
     s->d.attrs = reinterpret_cast<const float4*>(O.attrs);
     s->d.idOrder = O.idOrder;
     s->d.boxesNested = 1; // every box is the union of what lies below it
+    s->d.frontierOk = (bigLeaf == 0 && n <= kFrontierMaxIndex) ? 1 : 0;
     s->d.nWaveNodes = int32_t(nWide);
     s->d.waveRoot = 0;
     s->d.waveNodes = O.waveNodes;
@@ -4729,6 +4874,13 @@ int rtx_selfcheck_trig(const float* x, const float* y, size_t n, float* out)
 }
 
 #ifdef RTX_PROBE
+int rtx_debug_walk_probe(void* out, size_t nUnits) // nUnits x 8 words (WalkProbe) of the last deferred frame's walk
+{
+    if (nUnits > kProbeUnits)
+        return RTX_ERR_LIMIT;
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walkProbe), nUnits * sizeof(WalkProbe)) == hipSuccess ? RTX_OK : RTX_ERR_DEVICE;
+}
 int rtx_debug_probe(void* out, size_t nUnits)
 {
     if (nUnits > kProbeUnits)
