@@ -23,7 +23,7 @@ hip: raytracer_amd/librtx_hip.so raytracer_amd/libvalu_peak.so
 # diagnostic beside the product library: what a SIMD's vector ALU issues per cycle (bench.py's VALU roofline)
 raytracer_amd/libvalu_peak.so: tools/valu_peak.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -shared -o $@ tools/valu_peak.hip
-raytracer_amd/librtx_hip.so: raytracer_amd/csrc/rtx_hip.hip raytracer_amd/csrc/rtx_device.hpp include/rtx.h
+raytracer_amd/librtx_hip.so: raytracer_amd/csrc/rtx_hip.hip raytracer_amd/csrc/rtx_device.hpp raytracer_amd/csrc/rtx_build.hpp include/rtx.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ raytracer_amd/csrc/rtx_hip.hip
 
 host: raytracer_amd/librtx_host.so

@@ -89,7 +89,6 @@ struct DScene {
     int32_t nWaveNodes;
     int32_t waveRoot;        // 0 (the root node), ~first triangle when the root is a leaf
     int32_t boxesNested;     // every child box lies within its parent's box, the root's children within the root box
-    int32_t frontierOk;      // the four-wide records carry their leaf children's triangle counts and every index fits a frontier item (traverseFrontier)
     const float4* attrs;     // 4 x float4 per rtx_tri_attr
     const int32_t* idOrder;  // leaf-order record index of triangle id i (brute-force path)
     const rtx_material* mats;
@@ -103,6 +102,7 @@ struct DScene {
     int32_t nTris, nLights, nSpheres, nMaterials;
     int32_t rootRef;
     float rootLo[3], rootHi[3];
+    int32_t frontierOk;      // the four-wide records carry their leaf children's triangle counts and every index fits a frontier item (traverseFrontier)
 };
 
 constexpr int32_t kEmptyRoot = INT32_MIN;

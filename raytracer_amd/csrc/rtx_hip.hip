@@ -353,12 +353,6 @@ struct RenderArgs {
     int32_t W, H, driver, depth, samples, shadowSamples, glossyRays;
     uint32_t seed;
     float aperture, focal;
-    // RTX_DRIVER_COMPOSED: samples = timeSteps * lensSamples * jitterSamples, sample s = (t * lensSamples + l) *
-    // jitterSamples + j; drawsPerSample of the sequential engine per sample (time 1, pixel 2, lens 3, each only
-    // when its dimension is on)
-    int32_t lensSamples, jitterSamples, timeSteps, drawsPerSample;
-    int32_t transparency; // the transparency chain runs on every camera sample's ray (src/transparency.cpp:6-20)
-    int32_t normalise;    // how a pixel's samples become its colour: NORM_*
     // interleaved-tile partition
     int32_t tileSize, tileRank, tileWorld, tilesX, tilesY, tilesMine;
     int32_t compact; // 1: write this rank's tiles back to back, 0: Screen layout
@@ -405,6 +399,13 @@ struct RenderArgs {
     // not NULL: the launch does nothing unless this word is non-zero (the one-kernel path standing by
     // for a deferred frame whose pools ran over)
     const uint32_t* runIf;
+    // (last, so that the arguments above lie where the kernels' grouped argument loads have always found them)
+    // RTX_DRIVER_COMPOSED: samples = timeSteps * lensSamples * jitterSamples, sample s = (t * lensSamples + l) *
+    // jitterSamples + j; drawsPerSample of the sequential engine per sample (time 1, pixel 2, lens 3, each only
+    // when its dimension is on)
+    int32_t lensSamples, jitterSamples, timeSteps, drawsPerSample;
+    int32_t transparency; // the transparency chain runs on every camera sample's ray (src/transparency.cpp:6-20)
+    int32_t normalise;    // how a pixel's samples become its colour: NORM_*
 };
 RTX_DEV uint32_t costIndex(const RenderArgs& A, uint32_t block) { return (block & 63u) * A.costStride + (block >> 6); }
 
@@ -1211,6 +1212,123 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
     return result;
 }
 
+// computeLightContribution for point lights only (src/light.cpp:139-189 with :70-102 for the hard shadows), as the
+// lean paths use it: the shading point (hp, seen along rd), its material, the viewer-side normal.  Every lane of
+// the wave calls this together; `shade`: the lane has a point to shade.  TOGETHER: the shadow rays of a light
+// walk the tree together (they all start at the light), else lane by lane.
+template <int STACK, bool COUNT, bool TOGETHER>
+RTX_DEV V3 pointLightsLean(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool shade, V3 hp, V3 rd, V3 hitN, V3 albedo, V3 ks, float shin, V3 visN, LaneCounters& lc)
+{
+    V3 Lo = mk(0, 0, 0);
+    for (int li = 0; li < sc.nLights; li++) {
+        const rtx_light& L = sc.lights[li];
+        if (L.type != RTX_LIGHT_POINT)
+            continue; // segment / parallelogram lights only count with soft shadows (src/light.cpp:154,167)
+        const V3 pos = mk(L.p[0]);
+        V3 sh = mk(0, 0, 0);
+        if (shade)
+            sh = phong(pos, mk(L.c[0]), hp, rd, hitN, albedo, ks, shin);
+        if (f.enable_hard_shadow) {
+            lc.countShadow(shade);
+            const bool facing = shade && lightFacesSurface(pos, hp, visN);
+            lc.countTraced(facing);
+            float visible = 0.0f;
+            if (TOGETHER)
+                visible = lightVisibilityWave<STACK, COUNT>(sc, st, f, facing, pos, hp, lc.tc);
+            else if (facing)
+                visible = lightVisibility<STACK, COUNT>(sc, st, f, pos, hp, visN, lc.tc);
+            if (shade)
+                sh = sh * (facing ? visible : 0.0f);
+        }
+        if (shade)
+            Lo = Lo + sh;
+    }
+    return Lo;
+}
+
+// getFinalColor (src/render.cpp:16-66) with ONE level of mirror reflection under point lights: what the
+// reference's own drivers ask for when `recursive` is on (they pass depth 1 or 0, src/render.cpp:83,147,247)
+// and no glossy fan, area light, texture or environment map is in play.  Straight-line code like
+// tracePathLean -- the camera rays and their shadow rays walk the tree together, then the lanes whose
+// surface reflects (ks != 0, direction passes the test of src/render.cpp:31-38) trace their one child and its
+// shadow rays lane by lane (reflected rays of neighbouring pixels leave a curved surface every which way) --
+// so that a frame does not pay for the general state machine's 256 registers because a switch is on.
+// The arithmetic is tracePath's, term by term: child value added onto a zero, times 1 / count, times ks.
+template <int STACK, bool COUNT>
+RTX_DEV V3 tracePathLeanMirror(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, bool active, LaneCounters& lc)
+{
+    const DScene& sc = A.sc;
+    const rtx_features& f = A.f;
+    float t = kFltMax;
+    Hit hit;
+    lc.countPrimary(active);
+    lc.countTraced(active);
+    const bool any = intersectSceneWave<STACK, COUNT>(sc, st, f, active, o, d, t, hit, lc.tc);
+    const bool shade = any && f.enable_shading;
+    lc.countShaded(shade);
+    if (!anyLane(any))
+        return mk(0, 0, 0); // a miss is black without environment mapping (src/render.cpp:61-64)
+    V3 hp = mk(0, 0, 0), hitN = mk(0, 0, 0), albedo = mk(0, 0, 0), ks = mk(0, 0, 0), visN = mk(0, 0, 0), Lo = mk(0, 0, 0);
+    float shin = 1.f;
+    if (any) {
+        const rtx_material& m = sc.mats[hit.material];
+        hp = o + t * d;
+        hitN = hit.normal;
+        albedo = mk(m.kd);
+        ks = mk(m.ks);
+        shin = m.shininess;
+        visN = (dot(normalize(hitN), normalize(o - hp)) < -1e-6f) ? -hitN : hitN;
+        Lo = mk(m.kd); // shading disabled: the albedo (src/light.cpp:184-188)
+    }
+    const V3 lit = pointLightsLean<STACK, COUNT, true>(sc, st, f, shade, hp, d, hitN, albedo, ks, shin, visN, lc);
+    if (shade)
+        Lo = lit;
+    // src/render.cpp:22-52
+    const bool bounce = any && f.enable_recursive && A.depth > 0 && !(ks.x == 0.f && ks.y == 0.f && ks.z == 0.f);
+    if (!anyLane(bounce))
+        return Lo;
+    const V3 r = reflectDir(d, hitN);
+    const V3 childO = (o + d * t) + float(1e-5) * r;
+    const float cosinus = dot(normalize(r), normalize(hitN));
+    const float sinus = __builtin_sqrtf(1.0f - cosinus * cosinus);
+    const bool followed = bounce && cosinus > 0.0f && sinus > 0.0f;
+    V3 child = mk(0, 0, 0);
+    lc.countBounce(followed);
+    lc.countTraced(followed);
+    {
+        float ct = kFltMax;
+        Hit ch;
+        bool cAny = false;
+        if (followed)
+            cAny = intersectScene<STACK, COUNT>(sc, st, f, childO, r, ct, ch, lc.tc);
+        const bool cShade = cAny && f.enable_shading;
+        lc.countShaded(cShade);
+        V3 chp = mk(0, 0, 0), cN = mk(0, 0, 0), cAlbedo = mk(0, 0, 0), cKs = mk(0, 0, 0), cVisN = mk(0, 0, 0);
+        float cShin = 1.f;
+        if (cAny) {
+            const rtx_material& m = sc.mats[ch.material];
+            chp = childO + ct * r;
+            cN = ch.normal;
+            cAlbedo = mk(m.kd);
+            cKs = mk(m.ks);
+            cShin = m.shininess;
+            cVisN = (dot(normalize(cN), normalize(childO - chp)) < -1e-6f) ? -cN : cN;
+            child = mk(m.kd);
+        }
+        if (anyLane(cShade)) {
+            const V3 cLit = pointLightsLean<STACK, COUNT, false>(sc, st, f, cShade, chp, r, cN, cAlbedo, cKs, cShin, cVisN, lc);
+            if (cShade)
+                child = cLit;
+        }
+    }
+    if (!bounce)
+        return Lo;
+    // color += child; color *= 1 / count (0 * inf = NaN when the child was not followed); Lo + color * ks
+    const V3 acc = followed ? mk(0, 0, 0) + child : mk(0, 0, 0);
+    const V3 color = acc * (1.0f / float(followed ? 1 : 0));
+    return Lo + color * ks;
+}
+
 // ---- pass 1 of a deferred frame: the walk ---------------------------------------------
 // A lane's tape writer: entries go into chunks of kTapeChunk taken from the wave's pool.
 struct TapeWriter {
@@ -1671,10 +1789,10 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
 // frame (walkPath: radiance rays only, no pixel is written); 5: MODE 0 with every ray walking the
 // tree on its own
 template <int STACK, bool COUNT, int MODE>
-__global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A)
+__global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A) // (mode 10: tracePathLeanMirror)
 {
     constexpr bool FULL = MODE >= 1 && MODE <= 4; // (mode 9, the camera pass, needs none of either kind's machinery beyond ray generation)
-    constexpr bool BLUR = FULL || MODE == 6 || MODE == 7 || MODE == 9; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
+    constexpr bool BLUR = FULL || MODE == 6 || MODE == 7 || MODE == 9 || MODE == 10; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
     __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
     extern __shared__ int32_t sFan[]; // MODE 4: fanLevels * fan size * kBlock distances, then as many triangle records
@@ -1686,7 +1804,13 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
     const int lane = threadIdx.x & 63;
     const int slot = lane / A.lanesPerPixel, sub = lane % A.lanesPerPixel;
     const bool laneUsed = slot < A.pixelsPerUnit;
-    const bool averaging = A.normalise != NORM_SINGLE;
+    // (The composed driver's parameters are read only by the kernels that carry per-sample poses -- the host
+    // sends every composed frame to those -- and the other lean kernels go by the driver alone: their
+    // traversal loops run at the scalar registers' ceiling, and each kernel argument more that is kept
+    // across them costs reloads per trip, 5 % of the headline frame when this was one code path.)
+    const int normalise = (BLUR && A.driver == RTX_DRIVER_COMPOSED) ? A.normalise
+        : (A.driver == RTX_DRIVER_MRAYS || A.driver == RTX_DRIVER_DOF) ? int(NORM_RECIPROCAL) : A.driver == RTX_DRIVER_MOTION_BLUR ? int(NORM_DIVIDE) : int(NORM_SINGLE);
+    const bool averaging = normalise != NORM_SINGLE;
     // the lane that ends up holding its pixel's sum and stores it
     const bool writer = laneUsed && sub == A.lanesPerPixel - 1;
 
@@ -1816,7 +1940,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
                             d = rotate(qw, qv, dirCam);
                         }
                         break;
-                    case RTX_DRIVER_COMPOSED: {
+                    case RTX_DRIVER_COMPOSED: if (BLUR) {
                         // time step x lens sample x pixel jitter (see rtx_driver): the drivers' own pieces,
                         // their draws in the order time, pixel, lens
                         uint64_t rng = driverRngState(A, x, y, pixelIndex, sample, A.drawsPerSample);
@@ -1833,7 +1957,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
                             qx = float(float(x) + jx) / float(A.W) * 2.0f - 1.0f;
                             qy = float(float(y) + jy) / float(A.H) * 2.0f - 1.0f;
                         }
-                        if (BLUR && A.timeSteps > 1) { // (the host sends such frames to the kernels that carry the poses' trigonometry)
+                        if (A.timeSteps > 1) {
                             const V3 lookAt = mk(A.cam.look_at) + w * (mk(A.cam.look_at) - mk(A.prev.look_at));
                             const V3 euler = mk(A.cam.euler) + w * (mk(A.cam.euler) - mk(A.prev.euler));
                             const float dist = A.cam.distance + w * (A.cam.distance - A.prev.distance);
@@ -1883,7 +2007,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
                 walkPath<STACK, COUNT>(A, st, fan, o, d, active, key, storeIndex * uint32_t(A.samples) + uint32_t(sample), lc, unit);
                 continue; // (the pixel is written by resolveKernel)
             }
-            const V3 c = (MODE == 4 || MODE == 9) ? mk(0, 0, 0) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6 || MODE == 8, MODE == 8>(A, st, o, d, active, lc);
+            const V3 c = (MODE == 4 || MODE == 9) ? mk(0, 0, 0) : MODE == 10 ? tracePathLeanMirror<STACK, COUNT>(A, st, o, d, active, lc) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6 || MODE == 8, MODE == 8>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
             } else if (!anyLane(!(c.x == 0.f && c.y == 0.f && c.z == 0.f))) {
@@ -1930,7 +2054,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
         if (MODE != 4 && MODE != 9 && writer && storeIndex != 0xffffffffu) {
             {
                 const uint32_t outIndex = storeIndex;
-                const V3 px = normalisePixel(accum, A.normalise, A.samples);
+                const V3 px = normalisePixel(accum, normalise, A.samples);
                 float* dst = A.out + size_t(outIndex) * 3;
                 storeRgb(dst, px);
             }
@@ -2611,6 +2735,7 @@ struct rtx_scene {
     std::vector<std::array<float, 3>> lightPos; // p[0] of every light
     int numLevels = 0;
     bool hasEnv = false;
+    bool hasTextures = false;  // some material may carry a texture
     bool hasAreaLight = false; // a segment or parallelogram light
     std::vector<int32_t> lightTypes;
     int numLeaves = 0;         // leaves of the tree (the description's count, or the device builder's)
@@ -2821,6 +2946,7 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode, size_t
     }
 #define RTX_LAUNCH_MODES(CNT)                                                                                     \
     switch (mode) {                                                                                               \
+    case 10: RTX_LAUNCH(CNT, 10) break;                                                                           \
     case 9: RTX_LAUNCH(CNT, 9) break;                                                                             \
     case 8: RTX_LAUNCH(CNT, 8) break;                                                                             \
     case 7: RTX_LAUNCH(CNT, 7) break;                                                                             \
@@ -3302,7 +3428,10 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
 
     // the full kernel carries the reflection / transparency / area-light /
     // texture / environment machinery; the lean one is enough otherwise
-    const bool full = f->enable_recursive || f->enable_soft_shadow || f->enable_texture_mapping || f->enable_environment_mapping || A.transparency;
+    // (a switch that cannot take effect does not count: recursion with a ray depth of 0, which is what the
+    // reference's jittered and depth-of-field drivers pass; texture mapping in a scene without textures)
+    const bool recursiveOn = f->enable_recursive && A.depth > 0, texturesOn = f->enable_texture_mapping && scene->hasTextures;
+    const bool full = recursiveOn || f->enable_soft_shadow || texturesOn || f->enable_environment_mapping || A.transparency;
     // (glossy fans are traced side by side where a wave holds few pixels, i.e. under area
     // lights: with a full wave of paths the lanes' own traversals already run side by side)
     const bool fans = f->enable_recursive && f->enable_glossy_reflection && A.depth > 0 && A.glossyRays > 1 && A.glossyRays <= kFanMax
@@ -3335,14 +3464,18 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     const bool bundles = !lensOn && (!posesOn || swayPixels <= (sparse ? 256.0 : 64.0));
     const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : bundles && (A.lanesPerPixel >= 2 || sparse);
     // (the motion-blur driver's lean kernels carry the per-sample camera's trigonometry: modes 6 / 7)
-    const int mode = !full ? (posesOn ? (together ? 6 : 7) : (together ? 0 : 5)) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
+    // (every composed frame goes to the kernels that carry per-sample poses, the only lean ones that read its parameters)
+    // (one level of mirror reflection under point lights, coherent camera rays: the lean mirror path, mode 10)
+    const bool leanMirror = recursiveOn && !f->enable_glossy_reflection && A.depth == 1 && !f->enable_soft_shadow && !texturesOn && !f->enable_environment_mapping && !A.transparency
+        && together && !getenv("RTX_NO_LEAN_MIRROR");
+    const int mode = !full ? ((posesOn || composed) ? (together ? 6 : 7) : (together ? 0 : 5)) : leanMirror ? 10 : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
     // Mode 8 = mode 0 with every ray of the frame read from an origin's frame: the camera rays
     // of these drivers all start at the camera position, the shadow rays at their point light.
     // (The fixed-workspace entry point must not allocate and goes without: same arithmetic,
     // same pixels.)
     A.camFrame = OriginFrame { nullptr, nullptr };
     int launchMode = mode;
-    if (mode == 0 && !fixedArena && !originFramesOff() && (driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS || (composed && !lensOn && !posesOn)) && f->enable_accel_structure && scene->d.nTris > 0) {
+    if (mode == 0 && !fixedArena && !originFramesOff() && (driver == RTX_DRIVER_PLAIN || driver == RTX_DRIVER_MRAYS) && f->enable_accel_structure && scene->d.nTris > 0) {
         bool lightsHaveFrames = scene->lightTypes.size() <= size_t(kLightFrames);
         for (size_t li = 0; li < scene->lightTypes.size() && lightsHaveFrames; li++) // (other kinds do not count in the lean kernels)
             lightsHaveFrames = scene->lightTypes[li] != RTX_LIGHT_POINT || scene->d.lightFrame[li].nodes != nullptr;
@@ -3770,6 +3903,8 @@ int uploadShading(rtx_scene* s, const rtx_scene_desc* d)
     s->d.env = d->envmap;
     s->d.nLights = int32_t(d->n_lights);
     s->d.nEnvBins = int32_t(d->n_env_bins);
+    for (uint32_t i = 0; i < d->n_materials; i++)
+        s->hasTextures = s->hasTextures || d->materials[i].texture >= 0;
     for (uint32_t i = 0; i < d->n_lights; i++) {
         s->hasAreaLight = s->hasAreaLight || d->lights[i].type != RTX_LIGHT_POINT;
         s->lightTypes.push_back(d->lights[i].type);

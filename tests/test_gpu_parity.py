@@ -389,6 +389,44 @@ def test_origin_frames_do_not_change_frames(gpu_device, monkeypatch):
         gpu.close()
 
 
+def test_lean_mirror_path_equals_the_general_path(gpu_device, monkeypatch):
+    """One level of mirror reflection under point lights runs as straight-line code beside the lean path
+    (tracePathLeanMirror) instead of the general state machine: same frames bit for bit, same ray counts, for
+    the drivers that take it (plain, jittered with depth 1, motion blur), a scene with two point lights whose
+    mirrors some pixels see from behind, and against the oracle (NaN pixels, where the reference has them, in the
+    same places).
+    Switches that cannot take effect do not send a frame to the general path: recursion at depth 0, texture
+    mapping without textures."""
+    scene = cases.load_scene("cornell")
+    scene.lights = [abi.point_light((0.0, 0.58, 0.0), (1, 1, 1)), abi.point_light((0.3, 0.2, 0.4), (0.2, 0.3, 0.5))]
+    f = abi.features(**dict(cases.BASE, recursive=1))
+    cam = make_camera()
+    moved = make_camera(look_at=(0, 0.05, 0.1))
+    gpu, orc = GpuEngine(scene, f), OracleEngine(scene, f)
+    runs = [make_params(96, 80), make_params(96, 80, driver=abi.DRIVER_MRAYS, samples=4, ray_depth=1),
+            make_params(64, 64, driver=abi.DRIVER_MOTION_BLUR, samples=3, prev_camera=moved),
+            make_params(64, 48, driver=abi.DRIVER_COMPOSED, samples=2, time_steps=2, ray_depth=1, prev_camera=moved)]
+    for rp in runs:
+        lean = gpu.render(cam, f, rp)
+        counts = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce, gpu.stats.shaded_hits, gpu.stats.rays_traced)
+        assert gpu.stats.rays_bounce > 0
+        monkeypatch.setenv("RTX_NO_LEAN_MIRROR", "1")
+        general = gpu.render(cam, f, rp)
+        assert counts == (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.rays_bounce, gpu.stats.shaded_hits, gpu.stats.rays_traced)
+        monkeypatch.delenv("RTX_NO_LEAN_MIRROR")
+        assert np.array_equal(_bits(lean), _bits(general)), f"driver {rp.driver}: the lean mirror path's frame differs from the general path's"
+        want = orc.render(cam, f, rp)
+        assert counts[:3] == tuple(int(x) for x in orc.counters[:3])
+        assert_images_close(lean, want, f"lean mirror path, driver {rp.driver}")
+    # (the same kernel time class as without the switches: the frames are the lean path's)
+    plain = abi.features(**cases.BASE)
+    idle = abi.features(**dict(cases.BASE, recursive=1, texture_mapping=1))
+    rp = make_params(96, 80, driver=abi.DRIVER_MRAYS, samples=4)      # (depth 0: no reflection can happen)
+    assert np.array_equal(_bits(gpu.render(cam, idle, rp)), _bits(gpu.render(cam, plain, rp)))
+    gpu.close()
+    orc.close()
+
+
 def test_shadow_query_shortcuts_do_not_change_frames(gpu_device):
     """The shortened shadow queries must give the reference's answer in the regimes
     where they switch on and off: light closer than 0.2 to surfaces, coordinates

@@ -51,6 +51,8 @@ def main():
         ("area 64 + glossy depth 2", dict(soft_shadow=1, hard_shadow=0, recursive=1, glossy_reflection=1), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=2), area),
         ("area 64 + glossy depth 4", dict(soft_shadow=1, hard_shadow=0, recursive=1, glossy_reflection=1), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=4), area),
         ("mirror depth 4", dict(recursive=1), dict(), dict(driver=abi.DRIVER_PLAIN, ray_depth=4), None),
+        ("mirror ks 0.5 depth 1", dict(recursive=1), dict(), dict(samples=16, ray_depth=1), "shiny"),
+        ("mirror ks 0.5 depth 1 on the general path", dict(recursive=1), dict(), dict(samples=16, ray_depth=1), "shiny", "RTX_NO_LEAN_MIRROR"),
         ("transparency driver", dict(), dict(), dict(driver=abi.DRIVER_TRANSPARENCY), None),
         ("dof 16 samples", dict(), dict(), dict(driver=abi.DRIVER_DOF, samples=16), None),
         ("motion blur 7 steps", dict(), dict(), dict(driver=abi.DRIVER_MOTION_BLUR, samples=7, prev_camera=engine.device_camera(make_camera(rotation_degrees=(22, 18, 0)), 1920, 1080)), None),
@@ -78,7 +80,18 @@ def main():
         if only and name not in only:
             continue
         use = gpu
-        if len(var) > 4 and isinstance(var[4], str):
+        for k in ("RTX_NO_LEAN_MIRROR",):
+            os.environ.pop(k, None)
+        if len(var) > 5:
+            os.environ[var[5]] = "1"
+        if len(var) > 4 and var[4] == "shiny":
+            if "shiny" not in others:
+                shiny = dragon_scene()
+                for m in shiny.meshes:
+                    m.material[3:6] = 0.5
+                others["shiny"] = engine.GpuEngine(shiny, abi.features(**base))
+            use = others["shiny"]
+        elif len(var) > 4 and isinstance(var[4], str):
             if var[4] not in others:
                 others[var[4]] = engine.GpuEngine(winding_dragon_scene(), abi.features(**base), device_build=var[4].endswith("_dev"))
             use = others[var[4]]
