@@ -36,6 +36,9 @@ namespace {
 #ifndef RTX_LEAN_WAVES
 #define RTX_LEAN_WAVES 4
 #endif
+#ifndef RTX_LAYERS_WAVES
+#define RTX_LAYERS_WAVES 4
+#endif
 #ifndef RTX_FULL_WAVES
 #define RTX_FULL_WAVES 2
 #endif
@@ -1329,6 +1332,83 @@ RTX_DEV V3 tracePathLeanMirror(const RenderArgs& A, LaneStack<STACK>& st, V3 o, 
     return Lo + color * ks;
 }
 
+// calculateColorTransparency (src/transparency.cpp:6-20) around the lean path: the transparency chain of a
+// camera sample under point lights, no reflection.  Layer after layer -- trace, shade, and where the surface is
+// translucent keep (alpha, colour) and go on from just behind it (src/transparency.cpp:15) -- with the lanes
+// whose chain has ended sitting the later layers out; then the fold of tracePath, innermost first, the first
+// kMaxLayers layers kept one by one and deeper ones summed front to back.  Straight-line code at the lean
+// path's registers; the layers live in the lane's scratch memory, touched once per layer.  It pays where the
+// lanes of a wave end their chains together: the samples of one pixel (a jittered, lens or time-sampled frame);
+// 64 different pixels at one sample each lose lanes layer by layer and stay with the general state machine,
+// whose lanes in different layers share one traversal.
+template <int STACK, bool COUNT, bool TOGETHER>
+RTX_DEV V3 tracePathLeanLayers(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, bool active, LaneCounters& lc)
+{
+    const DScene& sc = A.sc;
+    const rtx_features& f = A.f;
+    float layerAlpha[kMaxLayers];
+    V3 layerColor[kMaxLayers];
+    int nLayers = 0;
+    float tailThrough = 1.0f;
+    V3 tailSum = mk(0, 0, 0), last = mk(0, 0, 0), from = o;
+    bool going = active;
+    while (anyLane(going)) {
+        float t = kFltMax;
+        Hit hit;
+        bool any = false;
+        lc.countPrimary(going);
+        lc.countTraced(going);
+        if (TOGETHER)
+            any = intersectSceneWave<STACK, COUNT>(sc, st, f, going, from, d, t, hit, lc.tc);
+        else if (going)
+            any = intersectScene<STACK, COUNT>(sc, st, f, from, d, t, hit, lc.tc);
+        const bool shade = any && f.enable_shading;
+        lc.countShaded(shade);
+        V3 hp = mk(0, 0, 0), hitN = mk(0, 0, 0), albedo = mk(0, 0, 0), ks = mk(0, 0, 0), visN = mk(0, 0, 0), value = mk(0, 0, 0);
+        float shin = 1.f, alpha = 1.0f;
+        if (any) {
+            const rtx_material& m = sc.mats[hit.material];
+            hp = from + t * d;
+            hitN = hit.normal;
+            albedo = mk(m.kd);
+            ks = mk(m.ks);
+            shin = m.shininess;
+            visN = (dot(normalize(hitN), normalize(from - hp)) < -1e-6f) ? -hitN : hitN;
+            value = mk(m.kd); // shading disabled: the albedo (src/light.cpp:184-188)
+            alpha = m.transparency;
+        }
+        if (anyLane(shade)) {
+            const V3 lit = pointLightsLean<STACK, COUNT, TOGETHER>(sc, st, f, shade, hp, d, hitN, albedo, ks, shin, visN, lc);
+            if (shade)
+                value = lit;
+        }
+        const bool more = going && any && alpha != 1.0f;
+        lc.countOverflow(more && nLayers == kMaxLayers); // (counted once per camera sample: reported in rtx_stats)
+        if (more) {
+            if (nLayers < kMaxLayers) {
+                layerAlpha[nLayers] = alpha;
+                layerColor[nLayers] = value;
+            } else {
+                tailSum = tailSum + (tailThrough * alpha) * value;
+                tailThrough = tailThrough * (1.0f - alpha);
+            }
+            nLayers++;
+            const float adv = float(double(t) + 1e-6);
+            from = from + mk(adv, adv, adv) * d;
+        } else if (going) {
+            last = value;
+        }
+        going = more;
+    }
+    V3 value = last;
+    if (nLayers > kMaxLayers)
+        value = tailSum + tailThrough * value;
+    // transparency * front + (1 - transparency) * behind, innermost first
+    for (int i = min(nLayers, kMaxLayers) - 1; i >= 0; i--)
+        value = layerAlpha[i] * layerColor[i] + (1.0f - layerAlpha[i]) * value;
+    return value;
+}
+
 // ---- pass 1 of a deferred frame: the walk ---------------------------------------------
 // A lane's tape writer: entries go into chunks of kTapeChunk taken from the wave's pool.
 struct TapeWriter {
@@ -1789,10 +1869,10 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
 // frame (walkPath: radiance rays only, no pixel is written); 5: MODE 0 with every ray walking the
 // tree on its own
 template <int STACK, bool COUNT, int MODE>
-__global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A) // (mode 10: tracePathLeanMirror)
+__global__ void __launch_bounds__(kBlock, (MODE == 11 || MODE == 12) ? RTX_LAYERS_WAVES : (MODE == 0 || MODE >= 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A) // (mode 10: tracePathLeanMirror; 11 / 12: tracePathLeanLayers, rays together / alone)
 {
     constexpr bool FULL = MODE >= 1 && MODE <= 4; // (mode 9, the camera pass, needs none of either kind's machinery beyond ray generation)
-    constexpr bool BLUR = FULL || MODE == 6 || MODE == 7 || MODE == 9 || MODE == 10; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
+    constexpr bool BLUR = FULL || MODE == 6 || MODE == 7 || MODE == 9 || MODE >= 10; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
     __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
     extern __shared__ int32_t sFan[]; // MODE 4: fanLevels * fan size * kBlock distances, then as many triangle records
@@ -2007,7 +2087,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 || MODE >= 5) ? RTX_LEAN_WA
                 walkPath<STACK, COUNT>(A, st, fan, o, d, active, key, storeIndex * uint32_t(A.samples) + uint32_t(sample), lc, unit);
                 continue; // (the pixel is written by resolveKernel)
             }
-            const V3 c = (MODE == 4 || MODE == 9) ? mk(0, 0, 0) : MODE == 10 ? tracePathLeanMirror<STACK, COUNT>(A, st, o, d, active, lc) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6 || MODE == 8, MODE == 8>(A, st, o, d, active, lc);
+            const V3 c = (MODE == 4 || MODE == 9) ? mk(0, 0, 0) : MODE == 10 ? tracePathLeanMirror<STACK, COUNT>(A, st, o, d, active, lc) : MODE >= 11 ? tracePathLeanLayers<STACK, COUNT, MODE == 11>(A, st, o, d, active, lc) : FULL ? tracePath<STACK, COUNT, true, MODE == 2, MODE == 3>(A, st, o, d, active, key, lc) : tracePathLean<STACK, COUNT, MODE == 0 || MODE == 6 || MODE == 8, MODE == 8>(A, st, o, d, active, lc);
             if (!averaging) {
                 accum = c;
             } else if (!anyLane(!(c.x == 0.f && c.y == 0.f && c.z == 0.f))) {
@@ -2946,6 +3026,8 @@ int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode, size_t
     }
 #define RTX_LAUNCH_MODES(CNT)                                                                                     \
     switch (mode) {                                                                                               \
+    case 12: RTX_LAUNCH(CNT, 12) break;                                                                           \
+    case 11: RTX_LAUNCH(CNT, 11) break;                                                                           \
     case 10: RTX_LAUNCH(CNT, 10) break;                                                                           \
     case 9: RTX_LAUNCH(CNT, 9) break;                                                                             \
     case 8: RTX_LAUNCH(CNT, 8) break;                                                                             \
@@ -3468,7 +3550,10 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
     // (one level of mirror reflection under point lights, coherent camera rays: the lean mirror path, mode 10)
     const bool leanMirror = recursiveOn && !f->enable_glossy_reflection && A.depth == 1 && !f->enable_soft_shadow && !texturesOn && !f->enable_environment_mapping && !A.transparency
         && together && !getenv("RTX_NO_LEAN_MIRROR");
-    const int mode = !full ? ((posesOn || composed) ? (together ? 6 : 7) : (together ? 0 : 5)) : leanMirror ? 10 : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
+    // (the transparency chain under point lights where a wave holds a few pixels' samples: the lean layers path, modes 11 / 12)
+    const bool leanLayers = A.transparency && !recursiveOn && !f->enable_soft_shadow && !texturesOn && !f->enable_environment_mapping
+        && A.lanesPerPixel >= (getenv("RTX_LEAN_LAYERS_FROM") ? atoi(getenv("RTX_LEAN_LAYERS_FROM")) : 4);
+    const int mode = !full ? ((posesOn || composed) ? (together ? 6 : 7) : (together ? 0 : 5)) : leanMirror ? 10 : leanLayers ? (together ? 11 : 12) : (f->enable_soft_shadow && f->enable_environment_mapping) ? 2 : fans ? 3 : 1;
     // Mode 8 = mode 0 with every ray of the frame read from an origin's frame: the camera rays
     // of these drivers all start at the camera position, the shadow rays at their point light.
     // (The fixed-workspace entry point must not allocate and goes without: same arithmetic,

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--copies", type=int, default=122)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--device-build", action="store_true", help="the tree built on the GPU (rtx_scene_build_device)")
     args = ap.parse_args()
     import torch
     from raytracer_amd import abi, engine
@@ -30,7 +31,7 @@ def main():
     print(f"scene: {scene.n_triangles} triangles in {len(scene.meshes)} meshes, made in {time.time() - t0:.1f} s", flush=True)
     f = abi.features(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
     t0 = time.time()
-    gpu = engine.GpuEngine(scene, f)
+    gpu = engine.GpuEngine(scene, f, device_build=args.device_build)
     print(f"host BVH build + flatten + upload: {time.time() - t0:.1f} s; {gpu.levels()} levels, {gpu.leaves()} leaves", flush=True)
     W, H = args.width, args.height
     dev = torch.device("cuda", 0)
@@ -43,6 +44,9 @@ def main():
         ("depth of field, 4 lens samples", make_params(W, H, driver=abi.DRIVER_DOF, samples=4, aperture=0.1, focal_length=2.0)),
         ("motion blur, 7 time steps", make_params(W, H, driver=abi.DRIVER_MOTION_BLUR, samples=7, prev_camera=prev)),
         ("transparency", make_params(W, H, driver=abi.DRIVER_TRANSPARENCY)),
+        # configs[4]'s combination: 4 lens samples x 7 time steps x 2 jittered positions, the transparency chain on every ray
+        ("composed 4 x 7 x 2 + transparency", make_params(W, H, driver=abi.DRIVER_COMPOSED, samples=2, lens_samples=4, time_steps=7, transparency=1, aperture=0.1, focal_length=2.0, prev_camera=prev)),
+        ("composed 4 x 7 x 2", make_params(W, H, driver=abi.DRIVER_COMPOSED, samples=2, lens_samples=4, time_steps=7, aperture=0.1, focal_length=2.0, prev_camera=prev)),
     ]
     for name, rp in runs:
         st = abi.Stats()

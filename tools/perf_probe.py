@@ -51,6 +51,11 @@ def main():
         ("area 64 + glossy depth 2", dict(soft_shadow=1, hard_shadow=0, recursive=1, glossy_reflection=1), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=2), area),
         ("area 64 + glossy depth 4", dict(soft_shadow=1, hard_shadow=0, recursive=1, glossy_reflection=1), dict(), dict(driver=abi.DRIVER_PLAIN, shadow_samples=64, glossy_rays=5, ray_depth=4), area),
         ("mirror depth 4", dict(recursive=1), dict(), dict(driver=abi.DRIVER_PLAIN, ray_depth=4), None),
+        ("composed 2x2x3", dict(), dict(), dict(driver=abi.DRIVER_COMPOSED, samples=2, lens_samples=2, time_steps=3, prev_camera=engine.device_camera(make_camera(rotation_degrees=(22, 18, 0)), 1920, 1080)), "glass"),
+        ("composed 2x2x3 + transparency", dict(), dict(), dict(driver=abi.DRIVER_COMPOSED, samples=2, lens_samples=2, time_steps=3, transparency=1, prev_camera=engine.device_camera(make_camera(rotation_degrees=(22, 18, 0)), 1920, 1080)), "glass"),
+        ("composed 2x2x3 + transparency on the general path", dict(), dict(), dict(driver=abi.DRIVER_COMPOSED, samples=2, lens_samples=2, time_steps=3, transparency=1, prev_camera=engine.device_camera(make_camera(rotation_degrees=(22, 18, 0)), 1920, 1080)), "glass", "RTX_LEAN_LAYERS_FROM"),
+        ("jittered 16 + transparency", dict(), dict(), dict(driver=abi.DRIVER_COMPOSED, samples=16, transparency=1), "glass"),
+        ("jittered 16 + transparency on the general path", dict(), dict(), dict(driver=abi.DRIVER_COMPOSED, samples=16, transparency=1), "glass", "RTX_LEAN_LAYERS_FROM"),
         ("mirror ks 0.5 depth 1", dict(recursive=1), dict(), dict(samples=16, ray_depth=1), "shiny"),
         ("mirror ks 0.5 depth 1 on the general path", dict(recursive=1), dict(), dict(samples=16, ray_depth=1), "shiny", "RTX_NO_LEAN_MIRROR"),
         ("transparency driver", dict(), dict(), dict(driver=abi.DRIVER_TRANSPARENCY), None),
@@ -80,11 +85,18 @@ def main():
         if only and name not in only:
             continue
         use = gpu
-        for k in ("RTX_NO_LEAN_MIRROR",):
+        for k in ("RTX_NO_LEAN_MIRROR", "RTX_LEAN_LAYERS_FROM"):
             os.environ.pop(k, None)
         if len(var) > 5:
-            os.environ[var[5]] = "1"
-        if len(var) > 4 and var[4] == "shiny":
+            os.environ[var[5]] = "1000"
+        if len(var) > 4 and var[4] == "glass":
+            if "glass" not in others:
+                glass = dragon_scene()
+                for m in glass.meshes:
+                    m.material[7] = 0.5     # translucent: camera rays go on through it (src/transparency.cpp:6-20)
+                others["glass"] = engine.GpuEngine(glass, abi.features(**base))
+            use = others["glass"]
+        elif len(var) > 4 and var[4] == "shiny":
             if "shiny" not in others:
                 shiny = dragon_scene()
                 for m in shiny.meshes:

@@ -30,7 +30,7 @@ def main():
 
     hip = engine.hip_lib()
     import bench
-    wargs = argparse.Namespace(workload=args.workload, width=1920, height=1080, spp=16, obj_npz=None)
+    wargs = argparse.Namespace(workload=args.workload, width=1920, height=1080, spp=16, obj_npz=None, obj=None)
     if args.workload == "big_scene":
         wargs.width, wargs.height = 3840, 2160
     wl = bench.workload(args.workload, wargs)
