@@ -59,6 +59,15 @@ struct Ray {
 // same order), made once per origin instead: the walk's arithmetic and results are bit for bit
 // the same.  (Whole copies rather than side arrays: the walk then needs no more scalar
 // registers than without a frame.)
+// A frame's triangle records are kFrameTriQuads float4 long: three quads of a PRETEST in front
+// of the six of DScene::waveTris.  With a_i = v_i - origin, the three vectors c_i = +-(a_i x
+// a_(i+1)) (sign: such that a ray from the origin towards the triangle's inside has
+// dot(d, c_i) > 0 for all three) tell by three dot products on which side of each edge a ray
+// from the origin passes: a ray with dot(d, c_i) < -M * max|d_k| for some i passes the
+// triangle by further than anything the reference's fp32 test could still take for a hit
+// (M: per triangle, see originFrameKernel), and the wave skips the plane division and the
+// edge tests of a triangle that all its rays pass that clearly -- most of a leaf's triangles
+// for the narrow bundle of a wave.  Quads: (c_0, M), (c_1, last-in-leaf flag: sign bit), (c_2, -).
 struct OriginFrame {
     const float4* nodes;
     const float4* tris;
@@ -106,6 +115,11 @@ struct DScene {
 };
 
 constexpr int32_t kEmptyRoot = INT32_MIN;
+#ifdef RTX_PROBE
+// diagnostic build: the wave-shared walk's triangle tests -- all, those some lane passes the plane stage of, those
+// some lane hits -- and its node visits, summed over the process
+__device__ unsigned long long g_waveWalkStats[8];
+#endif
 
 // ------------------------------------------------------------ primitives ----
 // Ray/box slab test, src/intersect.cpp:129-158.  Comparisons are written as
@@ -550,7 +564,8 @@ RTX_DEV int selectByMask(uint64_t m, int a, int b) { return __float_as_int(selec
 typedef float NF4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const NF4 UniformF4; // constant address space: uniform addresses load through the scalar cache
 RTX_DEV const UniformF4* uniformRecords(const float4* p) { return (const UniformF4*)(uintptr_t)p; }
-constexpr int kWaveNodeQuads = 8, kWaveTriQuads = 6;
+constexpr int kWaveNodeQuads = 8, kWaveTriQuads = 6, kFrameTriQuads = 9;
+constexpr float kPretestMin = 1e-12f, kPretestMax = 1e12f; // the pretest is off for rays and triangles whose magnitudes fall outside (products could leave fp32's range)
 
 // How a call of the wave-shared walk tests boxes:
 //   BOX_MIRRORED  childTestFinite's arithmetic in the mirrored frame (finite 1/d, one octant)
@@ -621,6 +636,9 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
     const UniformF4* const nodes = uniformRecords(REL ? fr.nodes : sc.waveNodes) + size_t(MODE == BOX_LITERAL ? 0u : oct) * size_t(uint32_t(sc.nWaveNodes)) * kWaveNodeQuads;
     const UniformF4* const tris = uniformRecords(REL ? fr.tris : sc.waveTris);
     const float inf = __builtin_inff();
+    // the pretest's threshold is M * -max|d_k| (no pretest for a direction of extreme magnitude)
+    const float dmax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float negDmax = REL ? (dmax > kPretestMin && dmax < kPretestMax ? -dmax : -inf) : 0.0f;
     int sp = 0;
     int32_t cur = __builtin_amdgcn_readfirstlane(sc.waveRoot);
     // Which lanes take part is kept as wave masks (aliveM: still looking for a hit; actM: inside
@@ -634,6 +652,8 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
 #ifdef RTX_PROBE
             tc.waveOuter += (threadIdx.x & 63u) == 0u;
             tc.outer += (actM >> (threadIdx.x & 63u)) & 1u;
+            if ((threadIdx.x & 63u) == 0u)
+                atomicAdd(&g_waveWalkStats[3], 1ull);
 #endif
             const UniformF4* p = nodes + size_t(uint32_t(cur)) * kWaveNodeQuads;
             const NF4 XL = p[0], XH = p[1], YL = p[2], YH = p[3], ZL = p[4], ZH = p[5], R = p[6];
@@ -673,14 +693,14 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
             }
         } else {
             // a leaf: its triangles one after the other, for the lanes that entered it
-            auto test = [&](const NF4& P, const NF4& A, const NF4& B, const NF4& E0, const NF4& E1, const NF4& C, uint32_t k) -> bool {
-                const bool last = __float_as_int(A.w) < 0; // (top bit of the id word)
+            // (candM: the lanes the triangle is tested for; last: the leaf ends with it)
+            auto test = [&](const NF4& P, const NF4& A, const NF4& B, const NF4& E0, const NF4& E1, const NF4& C, uint32_t k, uint64_t candM, bool last) -> bool {
 #ifdef RTX_PROBE
                 tc.waveInner += (threadIdx.x & 63u) == 0u;
                 tc.inner += (actM >> (threadIdx.x & 63u)) & 1u;
+                if ((threadIdx.x & 63u) == 0u)
+                    atomicAdd(&g_waveWalkStats[0], 1ull);
 #endif
-                if (COUNT)
-                    tc.triTests += uint32_t((actM >> (threadIdx.x & 63u)) & 1u);
                 // the plane part of triangleTest.  (Its `dn == 0` rejection needs no test of its own:
                 // the quotient is then an infinity or a NaN, which fails one of the two comparisons.)
                 const float dn = P.x * d.x + P.y * d.y + P.z * d.z;
@@ -691,7 +711,11 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                 }
                 const float th = num / dn;
                 const bool behind = th <= 0.f, nearer = th < t;
-                const uint64_t okM = actM & ~laneMask(behind) & laneMask(nearer);
+                const uint64_t okM = candM & ~laneMask(behind) & laneMask(nearer);
+#ifdef RTX_PROBE
+                if (okM && (threadIdx.x & 63u) == 0u)
+                    atomicAdd(&g_waveWalkStats[1], 1ull);
+#endif
                 if (okM) {
                     const V3 n = mk(P.x, P.y, P.z);
                     const V3 pt = o + th * d;
@@ -701,6 +725,10 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                     const float gamma = dot(n, cross(mk(C.x, C.y, C.z), e0));
                     const bool outside = alpha < 0 || beta < 0 || gamma < 0;
                     const uint64_t hitM = okM & ~laneMask(outside);
+#ifdef RTX_PROBE
+                    if (hitM && (threadIdx.x & 63u) == 0u)
+                        atomicAdd(&g_waveWalkStats[2], 1ull);
+#endif
                     if (hitM) {
                         t = selectByMask(hitM, th, t);
                         bestK = selectByMask(hitM, int(k), bestK);
@@ -713,20 +741,72 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                 }
                 return last || !actM;
             };
-            // Two whole records per round trip to memory (a leaf's triangles lie one behind the
-            // other): the walk of a wave that has the SIMD to itself -- the long units a frame ends
-            // on -- is a chain of such round trips, and fetching the edge vectors only after the
-            // plane test, triangle by triangle, made it four times as long.  The record behind a
-            // leaf's last one is another leaf's, or the array's padding, and is not looked at.
             uint32_t k = uint32_t(~cur);
-            for (;;) {
-                const UniformF4* q = tris + size_t(k) * kWaveTriQuads;
-                const NF4 P0 = q[0], A0 = q[1], B0 = q[2], E00 = q[3], E10 = q[4], C0 = q[5];
-                const NF4 P1 = q[6], A1 = q[7], B1 = q[8], E01 = q[9], E11 = q[10], C1 = q[11];
-                asm volatile("" ::"s"(B0.x), "s"(E00.x), "s"(E10.x), "s"(C0.x), "s"(P1.x), "s"(A1.x), "s"(B1.x), "s"(E01.x), "s"(E11.x), "s"(C1.x));
-                if (test(P0, A0, B0, E00, E10, C0, k) || test(P1, A1, B1, E01, E11, C1, k + 1))
-                    break;
-                k += 2;
+            if (REL) {
+                // With a frame: the pretests of two triangles per round trip to memory, and a whole
+                // record only for a triangle some lane's ray does not clearly pass.
+                auto pretested = [&](const UniformF4* q, const NF4& G0, const NF4& G1, const NF4& G2, uint32_t kk) -> bool {
+                    if (COUNT)
+                        tc.triTests += uint32_t((actM >> (threadIdx.x & 63u)) & 1u);
+                    const float e0 = G0.x * d.x + G0.y * d.y + G0.z * d.z;
+                    const float e1 = G1.x * d.x + G1.y * d.y + G1.z * d.z;
+                    const float e2 = G2.x * d.x + G2.y * d.y + G2.z * d.z;
+                    const bool clear = fminf(fminf(e0, e1), e2) < G0.w * negDmax; // passes the triangle by clearly
+                    const uint64_t candM = actM & ~laneMask(clear);
+                    const bool last = __float_as_int(G1.w) < 0;
+#ifdef RTX_PROBE
+                    if ((threadIdx.x & 63u) == 0u)
+                        atomicAdd(&g_waveWalkStats[4], 1ull);
+                    if (actM & ~candM) { // the whole test for the lanes the pretest drops: none may hit
+                        const NF4 P = q[3], A = q[4], B = q[5], E0 = q[6], E1 = q[7], C = q[8];
+                        const float th = P.w / (P.x * d.x + P.y * d.y + P.z * d.z);
+                        const V3 n = mk(P.x, P.y, P.z);
+                        const V3 pt = o + th * d;
+                        const V3 f0 = pt - mk(A.x, A.y, A.z), f1 = pt - mk(B.x, B.y, B.z);
+                        const float alpha = dot(n, cross(mk(E1.x, E1.y, E1.z), f1));
+                        const float beta = dot(n, cross(f0, mk(E0.x, E0.y, E0.z)));
+                        const float gamma = dot(n, cross(mk(C.x, C.y, C.z), f0));
+                        const bool hits = !(th <= 0.f) && th < t && !(alpha < 0 || beta < 0 || gamma < 0);
+                        const uint64_t wrongM = actM & ~candM & laneMask(hits);
+                        if (wrongM && (threadIdx.x & 63u) == 0u)
+                            atomicAdd(&g_waveWalkStats[5], (unsigned long long)__builtin_popcountll(wrongM));
+                    }
+#endif
+                    if (!candM)
+                        return last;
+                    const NF4 P = q[3], A = q[4], B = q[5], E0 = q[6], E1 = q[7], C = q[8];
+                    return test(P, A, B, E0, E1, C, kk, candM, last);
+                };
+                for (;;) {
+                    const UniformF4* q = tris + size_t(k) * kFrameTriQuads;
+                    const NF4 G00 = q[0], G01 = q[1], G02 = q[2];
+                    const NF4 G10 = q[kFrameTriQuads + 0], G11 = q[kFrameTriQuads + 1], G12 = q[kFrameTriQuads + 2];
+                    asm volatile("" ::"s"(G01.x), "s"(G02.x), "s"(G10.x), "s"(G11.x), "s"(G12.x));
+                    if (pretested(q, G00, G01, G02, k) || pretested(q + kFrameTriQuads, G10, G11, G12, k + 1))
+                        break;
+                    k += 2;
+                }
+            } else {
+                // Two whole records per round trip to memory (a leaf's triangles lie one behind the
+                // other): the walk of a wave that has the SIMD to itself -- the long units a frame ends
+                // on -- is a chain of such round trips, and fetching the edge vectors only after the
+                // plane test, triangle by triangle, made it four times as long.  The record behind a
+                // leaf's last one is another leaf's, or the array's padding, and is not looked at.
+                for (;;) {
+                    const UniformF4* q = tris + size_t(k) * kWaveTriQuads;
+                    const NF4 P0 = q[0], A0 = q[1], B0 = q[2], E00 = q[3], E10 = q[4], C0 = q[5];
+                    const NF4 P1 = q[6], A1 = q[7], B1 = q[8], E01 = q[9], E11 = q[10], C1 = q[11];
+                    asm volatile("" ::"s"(B0.x), "s"(E00.x), "s"(E10.x), "s"(C0.x), "s"(P1.x), "s"(A1.x), "s"(B1.x), "s"(E01.x), "s"(E11.x), "s"(C1.x));
+                    if (COUNT)
+                        tc.triTests += uint32_t((actM >> (threadIdx.x & 63u)) & 1u);
+                    if (test(P0, A0, B0, E00, E10, C0, k, actM, __float_as_int(A0.w) < 0))
+                        break;
+                    if (COUNT)
+                        tc.triTests += uint32_t((actM >> (threadIdx.x & 63u)) & 1u);
+                    if (test(P1, A1, B1, E01, E11, C1, k + 1, actM, __float_as_int(A1.w) < 0))
+                        break;
+                    k += 2;
+                }
             }
         }
         bool have = false;

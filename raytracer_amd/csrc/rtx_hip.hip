@@ -2610,10 +2610,24 @@ __global__ void __launch_bounds__(kBlock, RTX_FULL_WAVES) shadeKernel(ShadeArgs 
 // scatter gathered compact tile buffers into a Screen-layout frame
 // Makes an OriginFrame: thread i < 8 * nWide rewrites four-wide node i of the eight octant
 // copies (every plane minus the origin's coordinate in that copy's mirror image; references
-// and child count copied), thread j < nTris + 1 copies triangle record j (the padding record
-// included) with D - dot(n, origin) in place of D -- the operations traverseBvhWave makes per
-// ray without a frame.
-__global__ void __launch_bounds__(256) originFrameKernel(const float4* waveNodes, uint32_t nWide, const float4* waveTris, uint32_t nTris, float ox, float oy, float oz, float4* relNodes, float4* relTris)
+// and child count copied), thread j < nTris + 1 writes triangle record j (the padding record
+// included): the pretest's three quads, then the wave record with D - dot(n, origin) in place
+// of D -- the operations traverseBvhWave makes per ray without a frame.
+//
+// The pretest (see OriginFrame), in double from the fp32 vertices: c_i = a_i x a_(i+1) with
+// a_i = v_i - origin, all three negated if the ray towards the centroid has them negative.
+// A ray from the origin that meets the triangle's plane at p has dot(d, c_i) = |c_i| |d| rho /
+// |p - origin|, rho = p's distance from the plane through the origin and edge i, so dropping
+// rays with dot(d, c_i) < -|c_i| |d| F / h (h: the origin's distance from the triangle's plane,
+// <= |p - origin|) drops only rays whose p lies further than F outside edge i.  F bounds how far
+// outside the triangle the reference's fp32 test can still see a hit: the rounding of its plane
+// distance and of p (a few ulp of the coordinates' magnitude, |origin| + |a|; stretched along a
+// grazing ray by |p - origin| / h, which the division by h above already carries) and the tilt of
+// its fp32 unit normal against the exact one (a point at distance r <= `size` from v0 shifts by
+// r * tilt, stretched the same way), each taken 16 to 40 times over.  Max norms stand in for
+// the Euclidean ones (|c_i| |d| <= 3 cmax dmax).  M = inf (no pretest) for a triangle whose
+// numbers leave that reasoning: degenerate, origin in its plane, extreme magnitudes.
+__global__ void __launch_bounds__(256) originFrameKernel(const float4* waveNodes, uint32_t nWide, const float4* waveTris, const float4* tris, uint32_t nTris, float ox, float oy, float oz, float4* relNodes, float4* relTris)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 8u * nWide) {
@@ -2630,13 +2644,67 @@ __global__ void __launch_bounds__(256) originFrameKernel(const float4* waveNodes
         dst[7] = src[7];
     }
     if (i <= nTris) {
-        const float4* src = waveTris + size_t(i) * 6;
-        float4* dst = relTris + size_t(i) * 6;
+        const float4* src = waveTris + size_t(i) * kWaveTriQuads;
+        float4* dst = relTris + size_t(i) * kFrameTriQuads;
         const float4 P = src[0];
         const float no = P.x * ox + P.y * oy + P.z * oz;
-        dst[0] = make_float4(P.x, P.y, P.z, P.w - no);
+        dst[3] = make_float4(P.x, P.y, P.z, P.w - no);
         for (int q = 1; q < 6; q++)
-            dst[q] = src[q];
+            dst[3 + q] = src[q];
+        const float inf = __builtin_inff();
+        const float lastWord = __int_as_float(__float_as_int(src[1].w) < 0 ? int(0x80000000u) : 0);
+        double c[3][3] = {};
+        float M = inf;
+        if (i < nTris) {
+            // the triangle's record of the lane-by-lane walk holds the vertices: X = (v0.x, v1.x, v2.x, n.x), Y, Z
+            const float4 X = tris[size_t(i) * 4 + 0], Y = tris[size_t(i) * 4 + 1], Z = tris[size_t(i) * 4 + 2];
+            const double vx[3] = { X.x, X.y, X.z }, vy[3] = { Y.x, Y.y, Y.z }, vz[3] = { Z.x, Z.y, Z.z };
+            double a[3][3];
+            double amax = 0;
+            for (int v = 0; v < 3; v++) {
+                a[v][0] = vx[v] - double(ox), a[v][1] = vy[v] - double(oy), a[v][2] = vz[v] - double(oz);
+                amax = fmax(amax, fmax(fabs(a[v][0]), fmax(fabs(a[v][1]), fabs(a[v][2]))));
+            }
+            double cmax = 0;
+            for (int v = 0; v < 3; v++) {
+                const double* p = a[v];
+                const double* q = a[(v + 1) % 3];
+                c[v][0] = p[1] * q[2] - p[2] * q[1], c[v][1] = p[2] * q[0] - p[0] * q[2], c[v][2] = p[0] * q[1] - p[1] * q[0];
+                cmax = fmax(cmax, fmax(fabs(c[v][0]), fmax(fabs(c[v][1]), fabs(c[v][2]))));
+            }
+            const double g[3] = { (a[0][0] + a[1][0] + a[2][0]) / 3, (a[0][1] + a[1][1] + a[2][1]) / 3, (a[0][2] + a[1][2] + a[2][2]) / 3 };
+            double e[3];
+            for (int v = 0; v < 3; v++)
+                e[v] = g[0] * c[v][0] + g[1] * c[v][1] + g[2] * c[v][2];
+            const bool pos = e[0] > 0 && e[1] > 0 && e[2] > 0, neg = e[0] < 0 && e[1] < 0 && e[2] < 0;
+            // the exact unit normal, the origin's distance from the plane, the longest edge
+            const double ux = vx[1] - vx[0], uy = vy[1] - vy[0], uz = vz[1] - vz[0];
+            const double wx = vx[2] - vx[0], wy = vy[2] - vy[0], wz = vz[2] - vz[0];
+            const double zx = vx[2] - vx[1], zy = vy[2] - vy[1], zz = vz[2] - vz[1];
+            double nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
+            const double nl = sqrt(nx * nx + ny * ny + nz * nz);
+            const double size = sqrt(fmax(ux * ux + uy * uy + uz * uz, fmax(wx * wx + wy * wy + wz * wz, zx * zx + zy * zy + zz * zz)));
+            if ((pos || neg) && nl > 0) {
+                nx /= nl, ny /= nl, nz /= nl;
+                const double h = fabs(nx * a[0][0] + ny * a[0][1] + nz * a[0][2]);
+                const double tilt = fmax(fabs(nx - double(X.w)), fmax(fabs(ny - double(Y.w)), fabs(nz - double(Z.w)))) + 1e-6;
+                const double omax = fmax(fabs(double(ox)), fmax(fabs(double(oy)), fabs(double(oz))));
+                // (a plane constant that is not exactly dot(v0, n) moves the reference's plane along n)
+                const double dErr = fabs(double(P.w) - (double(X.w) * vx[0] + double(Y.w) * vy[0] + double(Z.w) * vz[0]));
+                const double F = 4e-6 * (omax + 3 * amax) + 4 * size * tilt + 4 * dErr;
+                const double m = 3 * cmax * fmax(1e-5, F / h); // (h == 0: inf)
+                const bool sane = cmax > double(kPretestMin) && cmax < double(kPretestMax) && tilt < 0.01 && m < 1e30 && m == m;
+                if (sane) {
+                    M = float(m) * 1.0001f;
+                    if (neg)
+                        for (int v = 0; v < 3; v++)
+                            c[v][0] = -c[v][0], c[v][1] = -c[v][1], c[v][2] = -c[v][2];
+                }
+            }
+        }
+        dst[0] = make_float4(float(c[0][0]), float(c[0][1]), float(c[0][2]), M);
+        dst[1] = make_float4(float(c[1][0]), float(c[1][1]), float(c[1][2]), lastWord);
+        dst[2] = make_float4(float(c[2][0]), float(c[2][1]), float(c[2][2]), 0.0f);
     }
 }
 
@@ -2847,12 +2915,12 @@ std::atomic<uint64_t> g_sceneIds { 0 };
 bool originFramesOff() { return getenv("RTX_NO_ORIGIN_FRAMES") != nullptr; } // diagnostic
 
 size_t frameNodeBytes(const rtx_scene* s) { return std::max<size_t>(size_t(uint32_t(s->d.nWaveNodes)) * 8, 1) * 8 * sizeof(float4); }
-size_t frameTriBytes(const rtx_scene* s) { return (size_t(uint32_t(s->d.nTris)) + 1) * 6 * sizeof(float4); }
+size_t frameTriBytes(const rtx_scene* s) { return (size_t(uint32_t(s->d.nTris)) + 1) * kFrameTriQuads * sizeof(float4); }
 void launchOriginFrame(const rtx_scene* s, const float* pos, float4* nodes, float4* tris, hipStream_t stream)
 {
     const uint32_t nWide = uint32_t(s->d.nWaveNodes), nTris = uint32_t(s->d.nTris);
     const uint64_t threads = std::max<uint64_t>(8ull * nWide, uint64_t(nTris) + 1);
-    hipLaunchKernelGGL(originFrameKernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, stream, s->d.waveNodes, nWide, s->d.waveTris, nTris, pos[0], pos[1], pos[2], nodes, tris);
+    hipLaunchKernelGGL(originFrameKernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, stream, s->d.waveNodes, nWide, s->d.waveTris, s->d.tris, nTris, pos[0], pos[1], pos[2], nodes, tris);
 }
 
 // The frames of the scene's first point lights (their shadow rays all start at the light),
@@ -5100,6 +5168,17 @@ int rtx_debug_walk_probe(void* out, size_t nUnits) // nUnits x 8 words (WalkProb
         return RTX_ERR_LIMIT;
     hipDeviceSynchronize();
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walkProbe), nUnits * sizeof(WalkProbe)) == hipSuccess ? RTX_OK : RTX_ERR_DEVICE;
+}
+int rtx_debug_wave_walk_stats(unsigned long long* out, int reset) // 8 counts of the wave-shared walk: whole triangle tests, plane stage passed, hit; node visits; pretests, lanes a pretest dropped that the whole test takes (must be 0)
+{
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtxd::g_waveWalkStats), 8 * sizeof(unsigned long long)) != hipSuccess)
+        return RTX_ERR_DEVICE;
+    if (reset) {
+        const unsigned long long zero[8] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(rtxd::g_waveWalkStats), zero, sizeof(zero));
+    }
+    return RTX_OK;
 }
 int rtx_debug_probe(void* out, size_t nUnits)
 {
