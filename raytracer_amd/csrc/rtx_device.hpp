@@ -67,7 +67,8 @@ struct Ray {
 // triangle by further than anything the reference's fp32 test could still take for a hit
 // (M: per triangle, see originFrameKernel), and the wave skips the plane division and the
 // edge tests of a triangle that all its rays pass that clearly -- most of a leaf's triangles
-// for the narrow bundle of a wave.  Quads: (c_0, M), (c_1, last-in-leaf flag: sign bit), (c_2, -).
+// for the narrow bundle of a wave.  Quads: (c_0.x, c_1.x, c_0.y, c_1.y), (c_0.z, c_1.z, c_2.x, c_2.y),
+// (c_2.z, M, last-in-leaf flag: sign bit, -).
 struct OriginFrame {
     const float4* nodes;
     const float4* tris;
@@ -589,35 +590,53 @@ enum BoxMode { BOX_MIRRORED = 0, BOX_OUTSIDE = 1, BOX_LITERAL = 2 };
 // differs from it in some axis has a negative im there (the frame's mirroring applied to its own
 // 1/d, an exact negation), and each axis' two products are put in order with min / max, which is
 // childTestFinite's arithmetic on the very same numbers.
-template <int MODE, bool ANYSIGN>
-RTX_DEV void childVisit(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 om, V3 im, float limit, uint64_t partM, float& key, uint64_t& enterM)
+// Two children (the halves of F2: slots 0 and 1, or 2 and 3, of a four-wide node) at a time: the
+// subtractions and products, which are the bulk of the test, as packed instructions.
+// `inside` (REL only): bits 0 and 1 say that the frame's origin lies inside child a / b (made
+// with the frame: every ray of the call starts there).
+template <int MODE, bool ANYSIGN, bool REL>
+RTX_DEV void childVisit2(F2 lox, F2 loy, F2 loz, F2 hix, F2 hiy, F2 hiz, V3 om, V3 im, float limit, uint64_t partM, uint32_t inside, float& keyA, uint64_t& enterA, float& keyB, uint64_t& enterB)
 {
     if (MODE == BOX_LITERAL) {
-        const bool h = childTest(mk(lox, loy, loz), mk(hix, hiy, hiz), om, im, limit, key);
-        enterM = laneMask(h) & partM; // (the literal test lets an origin inside the box in whatever the limit)
+        const bool ha = childTest(mk(lox.x, loy.x, loz.x), mk(hix.x, hiy.x, hiz.x), om, im, limit, keyA);
+        const bool hb = childTest(mk(lox.y, loy.y, loz.y), mk(hix.y, hiy.y, hiz.y), om, im, limit, keyB);
+        enterA = laneMask(ha) & partM; // (the literal test lets an origin inside the box in whatever the limit)
+        enterB = laneMask(hb) & partM;
         return;
     }
-    const float dlx = lox - om.x, dly = loy - om.y, dlz = loz - om.z;
-    const float dhx = hix - om.x, dhy = hiy - om.y, dhz = hiz - om.z;
-    float t0x = dlx * im.x, t0y = dly * im.y, t0z = dlz * im.z;
-    float t1x = dhx * im.x, t1y = dhy * im.y, t1z = dhz * im.z;
-    if (ANYSIGN) {
-        const float ax = fminf(t0x, t1x), ay = fminf(t0y, t1y), az = fminf(t0z, t1z);
-        t1x = fmaxf(t0x, t1x), t1y = fmaxf(t0y, t1y), t1z = fmaxf(t0z, t1z);
-        t0x = ax, t0y = ay, t0z = az;
-    }
-    const float first = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.0f));
-    const float second = fminf(fminf(t1x, t1y), t1z);
-    const uint64_t missM = laneMask(first > second);
-    key = first <= 0.0f ? second : first;
-    enterM = laneMask(!(limit < key)) & ~missM;
-    if (MODE != BOX_OUTSIDE) {
-        const uint64_t inM = laneMask(fmaxf(fmaxf(dlx, dly), dlz) <= 0.0f) & laneMask(fminf(fminf(dhx, dhy), dhz) >= 0.0f);
-        if (inM & partM) { // (rare below the first levels: most rays start outside most boxes)
-            key = selectByMask(inM, 0.0f, key);
-            enterM |= inM & partM;
+    // (with a frame the planes come with the origin already subtracted)
+    const F2 dlx = REL ? lox : lox - both(om.x), dly = REL ? loy : loy - both(om.y), dlz = REL ? loz : loz - both(om.z);
+    const F2 dhx = REL ? hix : hix - both(om.x), dhy = REL ? hiy : hiy - both(om.y), dhz = REL ? hiz : hiz - both(om.z);
+    F2 t0x = dlx * both(im.x), t0y = dly * both(im.y), t0z = dlz * both(im.z);
+    F2 t1x = dhx * both(im.x), t1y = dhy * both(im.y), t1z = dhz * both(im.z);
+    auto finish = [&](float ax, float ay, float az, float bx, float by, float bz, float lx, float ly, float lz, float hx, float hy, float hz, bool in, float& key, uint64_t& enterM) {
+        if (ANYSIGN) {
+            const float cx = fminf(ax, bx), cy = fminf(ay, by), cz = fminf(az, bz);
+            bx = fmaxf(ax, bx), by = fmaxf(ay, by), bz = fmaxf(az, bz);
+            ax = cx, ay = cy, az = cz;
         }
-    }
+        const float first = fmaxf(fmaxf(ax, ay), fmaxf(az, 0.0f));
+        const float second = fminf(fminf(bx, by), bz);
+        const uint64_t missM = laneMask(first > second);
+        key = first <= 0.0f ? second : first;
+        enterM = laneMask(!(limit < key)) & ~missM;
+        if (MODE != BOX_OUTSIDE) {
+            if (REL) {
+                if (in) { // (wave-uniform)
+                    key = 0.0f;
+                    enterM = partM;
+                }
+            } else {
+                const uint64_t inM = laneMask(fmaxf(fmaxf(lx, ly), lz) <= 0.0f) & laneMask(fminf(fminf(hx, hy), hz) >= 0.0f);
+                if (inM & partM) { // (rare below the first levels: most rays start outside most boxes)
+                    key = selectByMask(inM, 0.0f, key);
+                    enterM |= inM & partM;
+                }
+            }
+        }
+    };
+    finish(t0x.x, t0y.x, t0z.x, t1x.x, t1y.x, t1z.x, dlx.x, dly.x, dlz.x, dhx.x, dhy.x, dhz.x, (inside & 1u) != 0, keyA, enterA);
+    finish(t0x.y, t0y.y, t0z.y, t1x.y, t1y.y, t1z.y, dlx.y, dly.y, dlz.y, dhx.y, dhy.y, dhz.y, (inside & 2u) != 0, keyB, enterB);
 }
 
 // `alive`: the lanes of this call (passed the root box; for the mirrored modes: same octant,
@@ -663,10 +682,9 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
             const float limit = selectByMask(actM, t, -inf); // (a lane that sits this subtree out enters nothing)
             float k0, k1, k2, k3;
             uint64_t b0, b1, b2, b3; // the lanes that enter each child
-            childVisit<MODE, ANYSIGN>(XL.x, YL.x, ZL.x, XH.x, YH.x, ZH.x, om, im, limit, actM, k0, b0);
-            childVisit<MODE, ANYSIGN>(XL.y, YL.y, ZL.y, XH.y, YH.y, ZH.y, om, im, limit, actM, k1, b1);
-            childVisit<MODE, ANYSIGN>(XL.z, YL.z, ZL.z, XH.z, YH.z, ZH.z, om, im, limit, actM, k2, b2);
-            childVisit<MODE, ANYSIGN>(XL.w, YL.w, ZL.w, XH.w, YH.w, ZH.w, om, im, limit, actM, k3, b3);
+            const uint32_t inside = REL && MODE != BOX_OUTSIDE ? uint32_t(__float_as_int(p[7].w)) : 0u; // (which children hold the frame's origin)
+            childVisit2<MODE, ANYSIGN, REL>(F2 { XL.x, XL.y }, F2 { YL.x, YL.y }, F2 { ZL.x, ZL.y }, F2 { XH.x, XH.y }, F2 { YH.x, YH.y }, F2 { ZH.x, ZH.y }, om, im, limit, actM, inside, k0, b0, k1, b1);
+            childVisit2<MODE, ANYSIGN, REL>(F2 { XL.z, XL.w }, F2 { YL.z, YL.w }, F2 { ZL.z, ZL.w }, F2 { XH.z, XH.w }, F2 { YH.z, YH.w }, F2 { ZH.z, ZH.w }, om, im, limit, actM, inside >> 2, k2, b2, k3, b3);
             if (MODE == BOX_LITERAL || ANYSIGN) {
                 // (a test that orders each axis' two planes itself reads the inverted planes of
                 // an unused slot as all of space: go by the child count)
@@ -748,12 +766,12 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
                 auto pretested = [&](const UniformF4* q, const NF4& G0, const NF4& G1, const NF4& G2, uint32_t kk) -> bool {
                     if (COUNT)
                         tc.triTests += uint32_t((actM >> (threadIdx.x & 63u)) & 1u);
-                    const float e0 = G0.x * d.x + G0.y * d.y + G0.z * d.z;
-                    const float e1 = G1.x * d.x + G1.y * d.y + G1.z * d.z;
-                    const float e2 = G2.x * d.x + G2.y * d.y + G2.z * d.z;
-                    const bool clear = fminf(fminf(e0, e1), e2) < G0.w * negDmax; // passes the triangle by clearly
+                    // (not the reference's arithmetic: fused and packed operations are welcome)
+                    const F2 e01 = __builtin_elementwise_fma(F2 { G0.x, G0.y }, both(d.x), __builtin_elementwise_fma(F2 { G0.z, G0.w }, both(d.y), F2 { G1.x, G1.y } * both(d.z)));
+                    const float e2 = __builtin_fmaf(G1.z, d.x, __builtin_fmaf(G1.w, d.y, G2.x * d.z));
+                    const bool clear = fminf(fminf(e01.x, e01.y), e2) < G2.y * negDmax; // passes the triangle by clearly
                     const uint64_t candM = actM & ~laneMask(clear);
-                    const bool last = __float_as_int(G1.w) < 0;
+                    const bool last = __float_as_int(G2.z) < 0;
 #ifdef RTX_PROBE
                     if ((threadIdx.x & 63u) == 0u)
                         atomicAdd(&g_waveWalkStats[4], 1ull);
@@ -774,7 +792,9 @@ RTX_DEV void traverseBvhWave(const DScene& sc, LaneStack<STACK>& st, V3 o, V3 d,
 #endif
                     if (!candM)
                         return last;
+                    // (the whole record in one round trip: left alone, the loads sink behind the plane stage)
                     const NF4 P = q[3], A = q[4], B = q[5], E0 = q[6], E1 = q[7], C = q[8];
+                    asm volatile("" ::"s"(P.x), "s"(A.x), "s"(B.x), "s"(E0.x), "s"(E1.x), "s"(C.x));
                     return test(P, A, B, E0, E1, C, kk, candM, last);
                 };
                 for (;;) {

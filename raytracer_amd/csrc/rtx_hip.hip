@@ -39,6 +39,9 @@ namespace {
 #ifndef RTX_LAYERS_WAVES
 #define RTX_LAYERS_WAVES 4
 #endif
+#ifndef RTX_REL_WAVES
+#define RTX_REL_WAVES 6 // (mode 8 on trees of at most 16 levels, whose stacks leave the LDS for it: 80 vector registers; 0.585 -> 0.564 ms on the headline frame, 1.88 -> 1.71 ms at 64 samples against 4 waves)
+#endif
 #ifndef RTX_FULL_WAVES
 #define RTX_FULL_WAVES 2
 #endif
@@ -1142,6 +1145,20 @@ RTX_DEV V3 tracePath(const RenderArgs& A, LaneStack<STACK>& st, V3 camO, V3 camD
     return result;
 }
 
+// Visibility of point light li for the wave's shading points, the shadow rays walking the tree together: by the
+// light's origin frame if the scene has one for it (made at upload for the first kLightFrames point lights; the
+// choice is the same for the whole wave), which answers exactly as the scene's own records do.
+template <int STACK, bool COUNT>
+RTX_DEV float pointLightVisibilityWave(const DScene& sc, LaneStack<STACK>& st, const rtx_features& f, bool facing, V3 pos, V3 hp, int li, TraceCounters& tc)
+{
+    if (li < kLightFrames) {
+        const OriginFrame fr = li == 0 ? sc.lightFrame[0] : li == 1 ? sc.lightFrame[1] : li == 2 ? sc.lightFrame[2] : sc.lightFrame[3];
+        if (fr.nodes)
+            return lightVisibilityWave<STACK, COUNT, false, true>(sc, st, f, facing, pos, hp, tc, fr);
+    }
+    return lightVisibilityWave<STACK, COUNT>(sc, st, f, facing, pos, hp, tc);
+}
+
 // The same sample when nothing but point lights, Phong shading and hard shadows
 // are in play (no reflection, area light, texture, environment or transparency):
 // straight-line code with one traversal for the camera ray and one per point
@@ -1201,9 +1218,11 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
             const bool facing = shade && lightFacesSurface(pos, hp, visN);
             lc.countTraced(facing);
             float visible = 0.0f;
-            if (TOGETHER) // (the shadow rays start at the light: its frame, if it has one)
-                visible = lightVisibilityWave<STACK, COUNT, false, REL>(sc, st, f, facing, pos, hp, lc.tc,
+            if (TOGETHER && REL) // (the shadow rays start at the light: its frame, which the host has checked)
+                visible = lightVisibilityWave<STACK, COUNT, false, true>(sc, st, f, facing, pos, hp, lc.tc,
                     li == 0 ? sc.lightFrame[0] : li == 1 ? sc.lightFrame[1] : li == 2 ? sc.lightFrame[2] : sc.lightFrame[3]);
+            else if (TOGETHER)
+                visible = pointLightVisibilityWave<STACK, COUNT>(sc, st, f, facing, pos, hp, li, lc.tc);
             else if (facing)
                 visible = lightVisibility<STACK, COUNT>(sc, st, f, pos, hp, visN, lc.tc);
             if (shade)
@@ -1237,7 +1256,7 @@ RTX_DEV V3 pointLightsLean(const DScene& sc, LaneStack<STACK>& st, const rtx_fea
             lc.countTraced(facing);
             float visible = 0.0f;
             if (TOGETHER)
-                visible = lightVisibilityWave<STACK, COUNT>(sc, st, f, facing, pos, hp, lc.tc);
+                visible = pointLightVisibilityWave<STACK, COUNT>(sc, st, f, facing, pos, hp, li, lc.tc);
             else if (facing)
                 visible = lightVisibility<STACK, COUNT>(sc, st, f, pos, hp, visN, lc.tc);
             if (shade)
@@ -1247,6 +1266,13 @@ RTX_DEV V3 pointLightsLean(const DScene& sc, LaneStack<STACK>& st, const rtx_fea
             Lo = Lo + sh;
     }
     return Lo;
+}
+
+// Whether the wave's rays (`lane`: the lane has one, starting at o) may be walked by the camera position's
+// origin frame: there is one and every ray starts exactly there.
+RTX_DEV bool fromCamera(const RenderArgs& A, bool lane, V3 o)
+{
+    return A.camFrame.nodes != nullptr && !anyLane(lane && !(o.x == A.cam.position[0] && o.y == A.cam.position[1] && o.z == A.cam.position[2]));
 }
 
 // getFinalColor (src/render.cpp:16-66) with ONE level of mirror reflection under point lights: what the
@@ -1266,7 +1292,8 @@ RTX_DEV V3 tracePathLeanMirror(const RenderArgs& A, LaneStack<STACK>& st, V3 o, 
     Hit hit;
     lc.countPrimary(active);
     lc.countTraced(active);
-    const bool any = intersectSceneWave<STACK, COUNT>(sc, st, f, active, o, d, t, hit, lc.tc);
+    // (A.camFrame: the host makes one when every camera ray of the frame starts at the camera position)
+    const bool any = fromCamera(A, active, o) ? intersectSceneWave<STACK, COUNT, true>(sc, st, f, active, o, d, t, hit, lc.tc, A.camFrame) : intersectSceneWave<STACK, COUNT>(sc, st, f, active, o, d, t, hit, lc.tc);
     const bool shade = any && f.enable_shading;
     lc.countShaded(shade);
     if (!anyLane(any))
@@ -1351,17 +1378,20 @@ RTX_DEV V3 tracePathLeanLayers(const RenderArgs& A, LaneStack<STACK>& st, V3 o, 
     int nLayers = 0;
     float tailThrough = 1.0f;
     V3 tailSum = mk(0, 0, 0), last = mk(0, 0, 0), from = o;
-    bool going = active;
+    bool going = active, firstLayer = true;
     while (anyLane(going)) {
         float t = kFltMax;
         Hit hit;
         bool any = false;
         lc.countPrimary(going);
         lc.countTraced(going);
-        if (TOGETHER)
+        if (TOGETHER && firstLayer && fromCamera(A, going, from)) // (the chain's first ray starts at the camera position: its frame, if the host made one)
+            any = intersectSceneWave<STACK, COUNT, true>(sc, st, f, going, from, d, t, hit, lc.tc, A.camFrame);
+        else if (TOGETHER)
             any = intersectSceneWave<STACK, COUNT>(sc, st, f, going, from, d, t, hit, lc.tc);
         else if (going)
             any = intersectScene<STACK, COUNT>(sc, st, f, from, d, t, hit, lc.tc);
+        firstLayer = false;
         const bool shade = any && f.enable_shading;
         lc.countShaded(shade);
         V3 hp = mk(0, 0, 0), hitN = mk(0, 0, 0), albedo = mk(0, 0, 0), ks = mk(0, 0, 0), visN = mk(0, 0, 0), value = mk(0, 0, 0);
@@ -1869,11 +1899,15 @@ RTX_DEV void walkPath(const RenderArgs& A, LaneStack<STACK>& st, FanStore fan, V
 // frame (walkPath: radiance rays only, no pixel is written); 5: MODE 0 with every ray walking the
 // tree on its own
 template <int STACK, bool COUNT, int MODE>
-__global__ void __launch_bounds__(kBlock, (MODE == 11 || MODE == 12) ? RTX_LAYERS_WAVES : (MODE == 0 || MODE >= 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A) // (mode 10: tracePathLeanMirror; 11 / 12: tracePathLeanLayers, rays together / alone)
+__global__ void __launch_bounds__(kBlock, (MODE == 11 || MODE == 12) ? RTX_LAYERS_WAVES : (MODE == 8 && STACK <= kLdsStack) ? RTX_REL_WAVES : (MODE == 0 || MODE >= 5) ? RTX_LEAN_WAVES : MODE == 4 ? RTX_WALK_WAVES : RTX_FULL_WAVES) renderKernel(RenderArgs A) // (mode 10: tracePathLeanMirror; 11 / 12: tracePathLeanLayers, rays together / alone)
 {
     constexpr bool FULL = MODE >= 1 && MODE <= 4; // (mode 9, the camera pass, needs none of either kind's machinery beyond ray generation)
     constexpr bool BLUR = FULL || MODE == 6 || MODE == 7 || MODE == 9 || MODE >= 10; // (the motion-blur driver's per-sample cameras: kept out of the other lean kernels' registers)
-    __shared__ int32_t sStack[2 * LaneStack<STACK>::kLds * kBlock];
+    // (Mode 8 walks the tree only with the wave-shared walk, whose stack holds at most three entries per
+    // two levels of the binary tree -- a four-wide node spans two levels unless its children are leaves --
+    // i.e. 24 keys per lane for the 16-level kernels: LDS for five and six workgroups per CU.)
+    constexpr int kStackRows = (MODE == 8 && STACK <= kLdsStack) ? (3 * STACK + 1) / 2 : 2 * LaneStack<STACK>::kLds;
+    __shared__ int32_t sStack[kStackRows * kBlock];
     __shared__ int32_t sWaveRefs[(kBlock / 64) * 2 * STACK];
     extern __shared__ int32_t sFan[]; // MODE 4: fanLevels * fan size * kBlock distances, then as many triangle records
     __shared__ unsigned long long sBest[MODE == 4 ? kBlock : 1]; // MODE 4: traverseFrontier's best hit per ray
@@ -2611,7 +2645,7 @@ __global__ void __launch_bounds__(kBlock, RTX_FULL_WAVES) shadeKernel(ShadeArgs 
 // Makes an OriginFrame: thread i < 8 * nWide rewrites four-wide node i of the eight octant
 // copies (every plane minus the origin's coordinate in that copy's mirror image; references
 // and child count copied), thread j < nTris + 1 writes triangle record j (the padding record
-// included): the pretest's three quads, then the wave record with D - dot(n, origin) in place
+// included): the pretest's three quads (c_0 and c_1 side by side for packed arithmetic), then the wave record with D - dot(n, origin) in place
 // of D -- the operations traverseBvhWave makes per ray without a frame.
 //
 // The pretest (see OriginFrame), in double from the fp32 vertices: c_i = a_i x a_(i+1) with
@@ -2635,13 +2669,20 @@ __global__ void __launch_bounds__(256) originFrameKernel(const float4* waveNodes
         const float mx = (oct & 1u) ? -ox : ox, my = (oct & 2u) ? -oy : oy, mz = (oct & 4u) ? -oz : oz;
         const float4* src = waveNodes + size_t(i) * 8;
         float4* dst = relNodes + size_t(i) * 8;
+        float4 r[6];
         for (int q = 0; q < 6; q++) {
             const float m = q < 2 ? mx : q < 4 ? my : mz;
             const float4 v = src[q];
-            dst[q] = make_float4(v.x - m, v.y - m, v.z - m, v.w - m);
+            dst[q] = r[q] = make_float4(v.x - m, v.y - m, v.z - m, v.w - m);
         }
         dst[6] = src[6];
-        dst[7] = src[7];
+        // which children hold the origin: the walk's own test (every plane difference <= 0 below, >= 0 above), made here once
+        const float4 lo = make_float4(fmaxf(fmaxf(r[0].x, r[2].x), r[4].x), fmaxf(fmaxf(r[0].y, r[2].y), r[4].y), fmaxf(fmaxf(r[0].z, r[2].z), r[4].z), fmaxf(fmaxf(r[0].w, r[2].w), r[4].w));
+        const float4 hi = make_float4(fminf(fminf(r[1].x, r[3].x), r[5].x), fminf(fminf(r[1].y, r[3].y), r[5].y), fminf(fminf(r[1].z, r[3].z), r[5].z), fminf(fminf(r[1].w, r[3].w), r[5].w));
+        const int inside = (lo.x <= 0.0f && hi.x >= 0.0f ? 1 : 0) | (lo.y <= 0.0f && hi.y >= 0.0f ? 2 : 0) | (lo.z <= 0.0f && hi.z >= 0.0f ? 4 : 0) | (lo.w <= 0.0f && hi.w >= 0.0f ? 8 : 0);
+        float4 last = src[7];
+        last.w = __int_as_float(inside); // (the record's spare word)
+        dst[7] = last;
     }
     if (i <= nTris) {
         const float4* src = waveTris + size_t(i) * kWaveTriQuads;
@@ -2702,9 +2743,9 @@ __global__ void __launch_bounds__(256) originFrameKernel(const float4* waveNodes
                 }
             }
         }
-        dst[0] = make_float4(float(c[0][0]), float(c[0][1]), float(c[0][2]), M);
-        dst[1] = make_float4(float(c[1][0]), float(c[1][1]), float(c[1][2]), lastWord);
-        dst[2] = make_float4(float(c[2][0]), float(c[2][1]), float(c[2][2]), 0.0f);
+        dst[0] = make_float4(float(c[0][0]), float(c[1][0]), float(c[0][1]), float(c[1][1]));
+        dst[1] = make_float4(float(c[0][2]), float(c[1][2]), float(c[2][0]), float(c[2][1]));
+        dst[2] = make_float4(float(c[2][2]), M, lastWord, 0.0f);
     }
 }
 
@@ -2930,7 +2971,7 @@ int makeLightFrames(rtx_scene* s, hipStream_t stream)
     s->id = ++g_sceneIds;
     for (int i = 0; i < kLightFrames; i++)
         s->d.lightFrame[i] = OriginFrame { nullptr, nullptr };
-    if (s->d.nTris <= 0 || !s->d.waveTris)
+    if (s->d.nTris <= 0 || !s->d.waveTris || originFramesOff())
         return RTX_OK;
     for (size_t li = 0; li < s->lightTypes.size() && li < size_t(kLightFrames); li++) {
         if (s->lightTypes[li] != RTX_LIGHT_POINT)
@@ -3084,6 +3125,8 @@ int launchTrace(DeviceCtx* c, const TraceArgs& A, bool count)
 template <int STACK>
 int launchRender(DeviceCtx* c, const RenderArgs& A, bool count, int mode, size_t dynamicLds = 0)
 {
+    if (const char* e = getenv("RTX_EXTRA_LDS")) // diagnostic: fewer workgroups per CU (how the frame's time goes with the waves per SIMD)
+        dynamicLds += size_t(std::max(0, atoi(e)));
 #define RTX_LAUNCH(CNT, MODEV)                                                                                    \
     {                                                                                                             \
         const void* k = (const void*)renderKernel<STACK, CNT, MODEV>;                                             \
@@ -3639,6 +3682,12 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
                 launchMode = 8;
         }
     }
+    // The lean mirror and layers paths read their camera rays' walk from the camera position's frame when
+    // there is one (every camera ray of the frame must start there: no lens, no per-sample poses); their
+    // point lights' shadow rays go by the lights' frames wherever the scene has them.
+    if ((mode == 10 || mode == 11) && !fixedArena && !originFramesOff() && !lensOn && !posesOn && f->enable_accel_structure && scene->d.nTris > 0)
+        if (int rc = ensureCameraFrame(c, scene, cam->position, A.camFrame))
+            return rc;
     A.runIf = nullptr;
     A.defer = Deferred {};
     size_t walkLds = 0;

@@ -42,5 +42,26 @@ for scene in ("cornell", "monkey", "teapot", "cube", "transparency", "custom"):
     for cam_kw in ({}, dict(distance=0.7, rotation_degrees=(10, 200, 0)), dict(distance=6.0, rotation_degrees=(80, 45, 0)), dict(distance=0.05, look_at=(0.3, 0.2, 0.1))):
         bad += run(f"{scene} {cam_kw}", gpu, cam_kw, 512, 512, driver=abi.DRIVER_MRAYS, samples=4)
     gpu.close()
+# triangle soups (slivers, zero-area triangles, lights and cameras inside), also shrunk and blown up
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_fuzz as fz
+for seed in range(int(os.environ.get("RTX_PROBE_SOUPS", "40"))):
+    for scale in (1.0, 0.004, 3000.0):
+        scene, rng = fz.random_scene(seed)
+        for m in scene.meshes:
+            m.vertices[:, 0:3] *= np.float32(scale)
+        scene.lights = [abi.point_light(tuple(float(np.float32(v) * np.float32(scale)) for v in l.p[0]), tuple(l.c[0])) for l in scene.lights]
+        scene.spheres = []
+        try:
+            gpu = engine.GpuEngine(scene, f)
+        except Exception as e:      # (a development build takes trees of at most 16 levels)
+            print(f"soup {seed} x {scale}: {e}")
+            continue
+        for dist in (None, 0.15, 0.02):
+            cam = fz.random_camera(rng, dist)
+            kw = dict(fov_degrees=float(np.degrees(cam.fovy)), distance=float(cam.distance) * scale, look_at=tuple(float(v) * scale for v in cam.look_at),
+                      rotation_degrees=tuple(float(np.degrees(v)) for v in cam.euler))
+            bad += run(f"soup {seed} x {scale} d={dist}", gpu, kw, 256, 144, driver=abi.DRIVER_MRAYS, samples=4)
+        gpu.close()
 print("dropped lanes that hit, in all:", bad)
 sys.exit(1 if bad else 0)
