@@ -492,7 +492,8 @@ def main():
             counters = measured_counters(args.workload) if own_command else {}
             traffic = counters.get("hbm_bytes_per_launch")
             valu_instr = counters.get("SQ_INSTS_VALU")
-            vp = valu_peak()
+            kernel_waves = 4    # (the frame kernel's launch bound)
+            vp = valu_peak(kernel_waves)
             if valu_instr is not None and vp is not None:
                 # The kernel is bound by vector-ALU issue (pointer chasing through cache-resident records: no
                 # dense contraction, 4 % of the HBM rate).  Peak: a SIMD issues one wave64 instruction every
@@ -508,10 +509,10 @@ def main():
                                    # frames_in_flight frames on the chip at once
                                    "kernel_ms": round(kernel_ms, 4), "valu_instr_per_launch": int(valu_instr),
                                    "peak_is": f"0.5 wave64 instructions per cycle per SIMD x {simds} SIMDs x the clock measured now ({round(vp['clock_mhz'])} MHz)",
-                                   # the same rate against what a SIMD issues of the kernel's OWN instruction mix (a third of
-                                   # its instructions are 4.3-cycle kinds: compares, selects, min / max, lane reads), measured
-                                   # now on this GPU at the kernel's 4 waves per SIMD (tools/valu_peak.hip)
-                                   "frac_of_mix_ceiling": round(achieved / vp["chip_ginstr_s"], 4),
+                                   # the same rate against what a SIMD issues of the kernel's OWN instruction mix (three fifths of
+                                   # its instructions are 4.3-cycle kinds: packed products, compares, selects, min / max), measured
+                                   # now on this GPU at the kernel's waves per SIMD (tools/valu_peak.hip)
+                                   "frac_of_mix_ceiling": round(achieved / vp["chip_ginstr_s"], 4), "waves_per_simd": kernel_waves,
                                    "mix_ceiling_instr_per_cycle_per_simd": round(vp["ipc"], 4), "v_mul_f32_instr_per_cycle_per_simd": round(vp["ipc_mul"], 4),
                                    "counters_from": counters.get("file"), "counters_stale": counters.get("stale")}
                 if traced_all_ms is not None:

@@ -40,7 +40,12 @@ namespace {
 #define RTX_LAYERS_WAVES 4
 #endif
 #ifndef RTX_REL_WAVES
-#define RTX_REL_WAVES 6 // (mode 8 on trees of at most 16 levels, whose stacks leave the LDS for it: 80 vector registers; 0.585 -> 0.564 ms on the headline frame, 1.88 -> 1.71 ms at 64 samples against 4 waves)
+#define RTX_REL_WAVES 4
+// (Mode 8 on trees of at most 16 levels, whose 24-row stacks leave the LDS for six workgroups per CU.  At 6 waves per
+// SIMD (80 vector registers) the headline frame takes 0.57 ms against 0.585, 64 samples 1.71 against 1.88, the
+// screen-filling view 2.48 against 2.67 -- but the registers spilled per work unit become 0.7 GB of HBM writes and
+// 0.37 GB of reads per frame (75 and 96 MB at 4 waves: rocprofv3 WRITE_SIZE / FETCH_SIZE), and frames of one sample per
+// pixel get 10 % slower.  Not taken; -DRTX_REL_WAVES=6 builds it.)
 #endif
 #ifndef RTX_FULL_WAVES
 #define RTX_FULL_WAVES 2
@@ -1204,10 +1209,10 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
     }
     if (shade)
         result = mk(0, 0, 0);
-    for (int li = 0; li < sc.nLights; li++) {
+    auto light = [&](int li) {
         const rtx_light& L = sc.lights[li];
         if (L.type != RTX_LIGHT_POINT)
-            continue; // segment / parallelogram lights only count with soft shadows (src/light.cpp:154,167)
+            return; // segment / parallelogram lights only count with soft shadows (src/light.cpp:154,167)
         const V3 pos = mk(L.p[0]);
         V3 sh = mk(0, 0, 0);
         if (shade)
@@ -1230,7 +1235,9 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
         }
         if (shade)
             result = result + sh;
-    }
+    };
+    for (int li = 0; li < sc.nLights; li++)
+        light(li);
     return result;
 }
 

@@ -89,39 +89,38 @@ __global__ void __launch_bounds__(256) valuKernel(int iters, float seed, unsigne
             asm volatile("v_cmp_gt_f32 s[10:11], %0, %1\n s_nop 4" : : "v"(a0), "v"(b) : "s10", "s11");
             REP16(asm volatile("v_cndmask_b32 %0, %0, %4, s[10:11]\n v_cndmask_b32 %1, %1, %4, s[10:11]\n v_cndmask_b32 %2, %2, %4, s[10:11]\n v_cndmask_b32 %3, %3, %4, s[10:11]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "s10", "s11");)
         } else if (KIND == K_MIX) {
-            // Proportions of the frame kernel's traversal loop (the wave-shared walk: one four-wide
-            // node, a leaf's triangle pairs, the pop; static count over its ISA, 323 vector
-            // instructions): per 64 instructions 20 multiplies, 16 adds / subs, 2 fused multiply-adds,
-            // 3 moves, 2 integer operations (the fast kind), and 5 selects, 5 compares, 3 min3 / max3,
-            // 4 lane reads into scalar registers, div_scale + rcp + div_fmas + div_fixup of the plane
-            // test's division (the slow kind).
+            // Proportions of the frame kernel's traversal loop as the headline frame runs it (the wave-shared
+            // walk over origin frames; the loop's ISA weighted by the frame's counts of node visits, pretests,
+            // whole triangle tests and pops, 147 M of the launch's 252 M vector instructions): per 64
+            // instructions 11 multiplies, 7 adds / subs, 3 fused multiply-adds, 3 moves, 2 integer operations
+            // (the fast kind), and 9 packed multiplies, 2 packed fused multiply-adds, 3 max, 6 min3 / max3,
+            // 10 compares, 6 selects, a lane read and a part of the plane test's division (the slow kind).
             asm volatile(
-                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
-                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
-                "v_mul_f32 %0, %0, %11\n v_add_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_add_f32 %3, %3, %11\n"
-                "v_max3_f32 %0, %0, %11, %1\n v_min3_f32 %2, %2, %11, %3\n"
-                "v_cmp_ngt_f32 s[10:11], %0, %2\n v_cmp_nge_f32 vcc, %11, %0\n"
-                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
-                "v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %1, %1, %3, s[10:11]\n"
-                "v_mul_f32 %0, %0, %11\n v_add_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_add_f32 %3, %3, %11\n"
-                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
-                "v_cmp_nlt_f32 s[12:13], %1, %0\n v_cmp_nlt_f32 s[14:15], %3, %2\n"
-                "v_readlane_b32 s16, %8, 3\n v_readlane_b32 s17, %8, 7\n"
-                "v_mul_f32 %0, %0, %11\n v_add_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_add_f32 %3, %3, %11\n"
-                "v_cndmask_b32 %2, %2, %0, s[12:13]\n v_cndmask_b32 %3, %3, %1, s[14:15]\n"
-                "v_mul_f32 %0, %0, %11\n v_sub_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n"
-                "v_div_scale_f32 %2, s[10:11], %0, %0, %1\n v_rcp_f32 %3, %2\n"
-                "v_fma_f32 %3, %3, %11, %2\n v_fma_f32 %2, %3, %11, %2\n v_mul_f32 %0, %0, %11\n v_mul_f32 %1, %1, %11\n"
-                "v_cmp_lt_f32 vcc, %1, %0\n"
-                "v_div_fmas_f32 %3, %3, %2, %11\n v_div_fixup_f32 %2, %3, %0, %1\n"
-                "v_mul_f32 %0, %0, %11\n v_mul_f32 %2, %2, %11\n"
-                "v_max3_f32 %1, %1, %11, %0\n v_cndmask_b32 %3, %3, %2, vcc\n"
-                "v_readlane_b32 s18, %9, 11\n v_readlane_b32 s19, %9, 13\n"
-                "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n"
-                "v_lshl_add_u32 %8, %8, 2, %9\n v_add_u32 %9, %9, %8\n"
+                "v_pk_mul_f32 %4, %4, %10\n v_pk_mul_f32 %5, %5, %10\n v_pk_mul_f32 %6, %6, %10\n"
+                "v_max_f32 %0, %0, %11\n v_max3_f32 %1, %1, %11, %0\n v_min3_f32 %2, %2, %11, %3\n"
+                "v_cmp_ge_f32 s[10:11], %11, %1\n v_cmp_gt_f32 vcc, %1, %2\n"
+                "v_mul_f32 %3, %3, %11\n v_sub_f32 %0, %0, %11\n"
+                "v_cndmask_b32 %1, %1, %2, s[10:11]\n v_cmp_nlt_f32 s[12:13], %3, %1\n"
+                "v_pk_mul_f32 %7, %7, %10\n v_pk_mul_f32 %4, %4, %10\n v_pk_mul_f32 %5, %5, %10\n"
+                "v_max_f32 %0, %0, %11\n v_max3_f32 %1, %1, %11, %0\n v_min3_f32 %2, %2, %11, %3\n"
+                "v_cmp_ge_f32 s[10:11], %11, %1\n v_cmp_gt_f32 vcc, %1, %2\n"
+                "v_mul_f32 %3, %3, %11\n v_add_f32 %0, %0, %11\n"
+                "v_cndmask_b32 %1, %1, %2, s[10:11]\n v_cmp_nlt_f32 s[14:15], %3, %1\n"
+                "v_mov_b32 %0, %1\n v_lshl_add_u32 %8, %8, 2, %9\n v_cndmask_b32 %2, %2, %3, s[12:13]\n"
+                "v_pk_mul_f32 %6, %6, %10\n v_pk_fma_f32 %7, %7, %10, %6\n v_pk_fma_f32 %4, %4, %10, %7\n"
+                "v_mul_f32 %0, %0, %11\n v_fma_f32 %1, %1, %11, %0\n v_fma_f32 %2, %2, %11, %1\n"
+                "v_pk_mul_f32 %5, %5, %10\n v_mul_f32 %0, %0, %11\n v_cmp_lt_f32 vcc, %3, %0\n"
+                "v_mul_f32 %1, %1, %11\n v_mul_f32 %2, %2, %11\n v_mul_f32 %3, %3, %11\n v_add_f32 %0, %0, %1\n v_add_f32 %2, %2, %3\n"
+                "v_div_fixup_f32 %1, %1, %0, %2\n v_cmp_ge_f32 s[10:11], %11, %1\n v_cmp_lt_f32 s[12:13], %1, %3\n"
+                "v_mul_f32 %0, %0, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %11\n v_sub_f32 %1, %1, %11\n"
+                "v_mul_f32 %0, %0, %11\n v_mul_f32 %2, %2, %11\n v_sub_f32 %3, %3, %0\n v_fma_f32 %1, %1, %11, %2\n"
+                "v_max_f32 %0, %0, %11\n v_max3_f32 %1, %1, %11, %0\n v_min3_f32 %2, %2, %11, %3\n"
+                "v_cmp_gt_f32 vcc, %1, %2\n v_cndmask_b32 %3, %3, %2, vcc\n v_cndmask_b32 %0, %0, %1, s[14:15]\n"
+                "v_readlane_b32 s16, %8, 3\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_add_u32 %9, %9, %8\n"
+                "v_pk_mul_f32 %6, %6, %10\n v_cndmask_b32 %2, %2, %0, s[10:11]\n"
                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(i0), "+v"(i1)
                 : "v"(q), "v"(b)
-                : "vcc", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19");
+                : "vcc", "s10", "s11", "s12", "s13", "s14", "s15", "s16");
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
