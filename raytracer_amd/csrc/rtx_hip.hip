@@ -1228,6 +1228,9 @@ RTX_DEV V3 tracePathLean(const RenderArgs& A, LaneStack<STACK>& st, V3 o, V3 d, 
                     li == 0 ? sc.lightFrame[0] : li == 1 ? sc.lightFrame[1] : li == 2 ? sc.lightFrame[2] : sc.lightFrame[3]);
             else if (TOGETHER)
                 visible = pointLightVisibilityWave<STACK, COUNT>(sc, st, f, facing, pos, hp, li, lc.tc);
+            // (lane-by-lane frames keep their shadow rays lane by lane: walked together through the light's frame they
+            // win where triangles are large on the screen, 2.31 -> 2.12 ms for 16 lens samples on the headline scene, and
+            // lose where they are not, 5.2 -> 8.1 ms for 4 lens samples on the 10 M-triangle scene)
             else if (facing)
                 visible = lightVisibility<STACK, COUNT>(sc, st, f, pos, hp, visN, lc.tc);
             if (shade)
@@ -3661,7 +3664,19 @@ int renderImpl(const rtx_scene* scene, const rtx_camera* cam, const rtx_features
         if (!std::isfinite(swayPixels))
             swayPixels = INFINITY;
     }
-    const bool bundles = !lensOn && (!posesOn || swayPixels <= (sparse ? 256.0 : 64.0));
+    // (The lens samples of a pixel start all over the lens and cross at the focal point: how far they lie
+    // apart at the distance of what the camera looks at, in pixels.  Where triangles are large on the screen
+    // such a bundle still shares its way through the tree -- headline scene, 16 lens samples, aperture 0.1 focused at 2 from 3 away (25 pixels): 2.05
+    // against 2.37 ms lane by lane; on the 10 M-triangle scene at 3840x2160 it is 32 against 10 ms.)
+    double lensPixels = 0.0;
+    if (lensOn) {
+        const double dist = std::fabs(double(cam->distance)), focal = std::fabs(double(A.focal));
+        const double spread = 0.5 * std::sqrt(3.0) * std::fabs(double(A.aperture)) * (std::fabs(dist - focal) / std::max(focal, 1e-9) + 0.25);
+        lensPixels = spread / (std::max(dist, 1e-9) * std::max(double(cam->half_height), 1e-9)) * 0.5 * double(A.H);
+        if (!std::isfinite(lensPixels))
+            lensPixels = INFINITY;
+    }
+    const bool bundles = lensOn ? (sparse && swayPixels + lensPixels <= 64.0) : (!posesOn || swayPixels <= (sparse ? 256.0 : 64.0));
     const bool together = getenv("RTX_LEAN_WALK") ? atoi(getenv("RTX_LEAN_WALK")) != 0 : bundles && (A.lanesPerPixel >= 2 || sparse);
     // (the motion-blur driver's lean kernels carry the per-sample camera's trigonometry: modes 6 / 7)
     // (every composed frame goes to the kernels that carry per-sample poses, the only lean ones that read its parameters)
