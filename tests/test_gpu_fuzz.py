@@ -345,3 +345,75 @@ def test_nearest_texel_of_a_large_environment_map(gpu_device):
             assert_images_close(gpu.render(cam, f, rp), orc.render(cam, f, rp), f"mapping {mapping}, camera {rot}")
         gpu.close()
         orc.close()
+
+
+def test_pretest_of_origin_frames_at_its_limits(gpu_device):
+    """The records made per ray origin (camera position, point lights) carry a conservative pretest per
+    triangle; what it may skip must be work whose answer was "no hit".  Geometry chosen against it: a
+    tessellated plane seen and lit at grazing angles (most rays pass close to an edge), a camera and a
+    light IN the plane of triangles, a camera a hair above a triangle much larger than its distance, a
+    fan of slivers around one vertex with the camera looking at that vertex, and the same at scales where
+    the pretest's products would leave fp32's range and it must stand aside."""
+    def grid_plane(n, size, wobble, rng):
+        xs = np.linspace(-size, size, n + 1)
+        p = np.array([(x, wobble * rng.standard_normal(), z) for z in xs for x in xs], np.float32)
+        v = np.zeros((len(p), 8), np.float32)
+        v[:, 0:3] = p
+        v[:, 3:6] = (0, 1, 0)
+        t = []
+        for j in range(n):
+            for i in range(n):
+                a = j * (n + 1) + i
+                t += [[a, a + 1, a + n + 2], [a, a + n + 2, a + n + 1]]
+        return v, np.array(t, np.uint32)
+
+    def sliver_fan(n, rng):
+        ang = np.sort(rng.random(n) * 2 * np.pi)
+        v = np.zeros((n * 3, 8), np.float32)
+        for k in range(n):
+            a0, a1 = ang[k], ang[k] + 1e-3 + 0.3 * rng.random() ** 4
+            v[3 * k + 0, 0:3] = (0.05, 0.1, -0.02)
+            v[3 * k + 1, 0:3] = (0.05 + np.cos(a0), 0.1 + 0.2 * rng.random(), -0.02 + np.sin(a0))
+            v[3 * k + 2, 0:3] = (0.05 + np.cos(a1), 0.1 + 0.2 * rng.random(), -0.02 + np.sin(a1))
+        v[:, 3:6] = (0, 1, 0)
+        return v, np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
+
+    rng = np.random.default_rng(77)
+    mat = (0.7, 0.6, 0.3, 0.2, 0.2, 0.2, 8.0, 1.0)
+    flat, bumpy, fan, big = SceneData(), SceneData(), SceneData(), SceneData()
+    flat.add_mesh(*grid_plane(24, 1.0, 0.0, rng), mat)
+    bumpy.add_mesh(*grid_plane(24, 1.0, 0.004, rng), mat)
+    fan.add_mesh(*sliver_fan(150, rng), mat)
+    v = np.zeros((3, 8), np.float32)
+    v[:, 0:3] = [(-40, 0, -40), (40, 0, -35), (0, 0, 45)]
+    v[:, 3:6] = (0, 1, 0)
+    big.add_mesh(v, [[0, 1, 2]], mat)
+    big.add_mesh(*grid_plane(6, 0.3, 0.02, rng), (0.2, 0.5, 0.8, 0, 0, 0, 1.0, 1.0))
+    for s in (flat, bumpy, fan, big):
+        # a light well above, one grazing, one exactly in the plane y = 0 of the flat meshes
+        s.lights = [abi.point_light((0.3, 1.5, 0.4)), abi.point_light((1.8, 0.02, -0.3), (0.5, 0.5, 0.9)), abi.point_light((0.2, 0.0, 0.1), (0.3, 0.9, 0.3))]
+    cams = {
+        "from above": make_camera(distance=2.5, rotation_degrees=(60, 30, 0)),
+        "grazing": make_camera(distance=2.2, rotation_degrees=(1.5, 200, 0), look_at=(0, 0.0, 0)),
+        "in the plane": make_camera(distance=1.7, rotation_degrees=(0, 75, 0), look_at=(0, 0.0, 0)),
+        "a hair above": make_camera(distance=0.6, rotation_degrees=(0.4, 10, 0), look_at=(0.3, 0.0, 0.2)),
+        "at the fan's vertex": make_camera(distance=0.8, rotation_degrees=(35, 140, 0), look_at=(0.05, 0.1, -0.02)),
+    }
+    f = abi.features(**cases.BASE)
+    for sname, scene in (("flat grid", flat), ("bumpy grid", bumpy), ("sliver fan", fan), ("huge triangle", big)):
+        for scale in (1.0, 1e-5, 3e6):
+            sc = SceneData()
+            for m in scene.meshes:
+                vv = m.vertices.copy()
+                vv[:, 0:3] *= np.float32(scale)
+                sc.add_mesh(vv, m.triangles, m.material)
+            sc.lights = [abi.point_light(tuple(float(np.float32(x) * np.float32(scale)) for x in l.p[0]), tuple(l.c[0])) for l in scene.lights]
+            gpu, orc = GpuEngine(sc, f), OracleEngine(sc, f)
+            for cname, cam0 in cams.items():
+                cam = make_camera(fov_degrees=float(np.degrees(cam0.fovy)), distance=float(np.float32(cam0.distance) * np.float32(scale)),
+                                  look_at=tuple(float(np.float32(x) * np.float32(scale)) for x in cam0.look_at), rotation_degrees=tuple(float(np.degrees(x)) for x in cam0.euler))
+                what = f"{sname} x {scale}, {cname}"
+                check_frame(gpu, orc, cam, f, make_params(160, 90, driver=abi.DRIVER_MRAYS, samples=4), what + ", 4 samples", ties=2)
+                check_frame(gpu, orc, cam, f, make_params(96, 54), what + ", plain", ties=1)
+            gpu.close()
+            orc.close()
