@@ -13,14 +13,15 @@ hip = engine.hip_lib()
 f = abi.features(shading=1, hard_shadow=1, normal_interp=1, accel_structure=1, bvh_sah_binning=1)
 gpu = engine.GpuEngine(dragon_scene(), f)
 cam = engine.device_camera(make_camera(), 1920, 1080)
+SPP = int(os.environ.get("RTX_PROBE_SPP", "16"))   # (samples per pixel of the probed frame)
 for world in (1, 8):
-    rp = make_params(1920, 1080, driver=abi.DRIVER_MRAYS, samples=16, tile_size=32, tile_rank=0, tile_world=world)
+    rp = make_params(1920, 1080, driver=abi.DRIVER_MRAYS, samples=SPP, tile_size=32, tile_rank=0, tile_world=world)
     per = hip.rtx_tiles_per_rank(C.byref(rp))
     tiles = torch.zeros((per, 32, 32, 3), dtype=torch.float32, device="cuda")
     st = abi.Stats()
     for _ in range(4):
         assert hip.rtx_render_tiles_device(gpu.device_scene(), C.byref(cam), C.byref(f), C.byref(rp), C.c_void_p(tiles.data_ptr()), C.byref(st)) == 0
-    n = per * 32 * 32 // 4
+    n = per * 32 * 32 // max(1, 64 // min(SPP, 64))
     t = np.zeros((n, 4), np.uint32)
     assert hip.rtx_debug_probe(t.ctypes.data_as(C.c_void_p), C.c_size_t(n)) == 0
     t = t[t[:, 0] > 0]    # units that ran (culled units do not report)
