@@ -330,7 +330,7 @@ int rtx_render_device(const rtx_scene* scene, const rtx_camera* camera, const rt
  * the camera-relative records of the pinhole drivers are allocated per scene, so this entry
  * point renders such frames with the one-kernel form and the plain records (measured at
  * 1920x1080: one parallelogram light with 64 samples 3.8 against 2.6 ms, with glossy
- * reflections to depth 4 82 against 17 ms, the headline frame 0.77 against 0.73 ms). */
+ * reflections to depth 4 82 against 17 ms, the headline frame 0.67 against 0.59 ms). */
 int rtx_render_device_static(const rtx_scene* scene, const rtx_camera* camera, const rtx_features* features,
                              const rtx_render_params* params, float* d_out_rgb, rtx_stats* stats);
 /* Same, but this rank's tiles are written compactly: tile k of this rank
