@@ -37,6 +37,8 @@ def main():
         ("4 spp", dict(), dict(), dict(samples=4)),
         ("64 spp", dict(), dict(), dict(samples=64)),
         ("plain driver", dict(), dict(), dict(driver=abi.DRIVER_PLAIN)),
+        ("plain driver close-up d=1.2", dict(), dict(distance=1.2), dict(driver=abi.DRIVER_PLAIN)),
+        ("4 spp close-up d=1.2", dict(), dict(distance=1.2), dict(samples=4)),
         ("recursive (general path)", dict(recursive=1), dict(), dict(samples=16)),
     ]
     # configs[2]-like: one parallelogram light, soft shadows, glossy reflections (general kernel)
