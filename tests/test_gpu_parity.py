@@ -372,12 +372,29 @@ def test_origin_frames_do_not_change_frames(gpu_device, monkeypatch):
         got = []
         for cam in cams:
             got.append((gpu.render(cam, f, rp), (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.shaded_hits, gpu.stats.rays_traced)))
+        # (the lights' frames are made with the scene: the plain records' frames come from a scene uploaded with the switch set)
         monkeypatch.setenv("RTX_NO_ORIGIN_FRAMES", "1")
+        bare = GpuEngine(scene, f, device_build=device_build)
         for i, cam in enumerate(cams):
-            plain = gpu.render(cam, f, rp)
-            counts = (gpu.stats.rays_primary, gpu.stats.rays_shadow, gpu.stats.shaded_hits, gpu.stats.rays_traced)
+            plain = bare.render(cam, f, rp)
+            counts = (bare.stats.rays_primary, bare.stats.rays_shadow, bare.stats.shaded_hits, bare.stats.rays_traced)
             assert np.array_equal(_bits(got[i][0]), _bits(plain)), f"{name}: frame {i} differs from the frame on the plain records"
             assert got[i][1] == counts, f"{name}: frame {i} counts {got[i][1]} vs {counts}"
+        # the other lean kernels take the lights' frames for their shadow rays (and the camera's where all camera rays
+        # start at the camera): time-sampled, lens-sampled and composed frames, one mirror bounce, the transparency chain
+        others = [(f, make_params(120, 72, driver=abi.DRIVER_MOTION_BLUR, samples=5, prev_camera=cams[2])),
+                  (f, make_params(120, 72, driver=abi.DRIVER_DOF, samples=6, aperture=0.05, focal_length=2.5)),
+                  (f, make_params(96, 54, driver=abi.DRIVER_COMPOSED, samples=2, lens_samples=2, time_steps=2, prev_camera=cams[2])),
+                  (abi.features(**dict(cases.BASE, recursive=1)), make_params(120, 72, driver=abi.DRIVER_MRAYS, samples=8, ray_depth=1)),
+                  (f, make_params(120, 72, driver=abi.DRIVER_COMPOSED, samples=8, transparency=1))]
+        for j, (feat, params) in enumerate(others):
+            monkeypatch.setenv("RTX_NO_ORIGIN_FRAMES", "1")
+            plain = bare.render(cams[1], feat, params)
+            monkeypatch.delenv("RTX_NO_ORIGIN_FRAMES")
+            framed = gpu.render(cams[1], feat, params)
+            assert np.array_equal(_bits(framed), _bits(plain)), f"{name}: lean frame {j} differs from the frame on the plain records"
+        monkeypatch.setenv("RTX_NO_ORIGIN_FRAMES", "1")
+        bare.close()
         monkeypatch.delenv("RTX_NO_ORIGIN_FRAMES")
         assert np.array_equal(_bits(got[0][0]), _bits(got[3][0])) and got[0][1][1] > 0 and np.nanmax(got[0][0]) > 0
         assert not np.array_equal(_bits(got[0][0]), _bits(got[1][0]))
